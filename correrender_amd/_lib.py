@@ -1,0 +1,79 @@
+"""ctypes binding of libcorrfield.so (include/corrfield.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+class CorrFieldError(RuntimeError):
+    """A non-zero status from the C ABI (the reference reports the same conditions through
+    sgl::Logfile::throwError, e.g. src/Volume/VolumeData.cpp:1217-1221)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libcorrfield error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class CrfParams(C.Structure):
+    _fields_ = [
+        ("measure", C.c_int32),
+        ("ref_x", C.c_int32), ("ref_y", C.c_int32), ("ref_z", C.c_int32),
+        ("k", C.c_int32),
+        ("kraskov_estimator_index", C.c_int32),
+        ("num_bins", C.c_int32),
+        ("min_ref", C.c_float), ("max_ref", C.c_float),
+        ("min_query", C.c_float), ("max_query", C.c_float),
+        ("reference_values", C.POINTER(C.c_float)),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+# every symbol include/corrfield.h declares: name -> (restype, argtypes)
+_VOIDP = C.c_void_p
+SYMBOLS = {
+    "crf_abi_version": (C.c_int, []),
+    "crf_create": (C.c_int, [C.c_int, C.POINTER(_VOIDP)]),
+    "crf_destroy": (None, [_VOIDP]),
+    "crf_last_error": (C.c_char_p, [_VOIDP]),
+    "crf_set_grid": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crf_upload_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_bind_members_device": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crf_gather_reference": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "crf_gather_reference_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
+    "crf_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
+    "crf_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, _VOIDP, _VOIDP]),
+    "crf_set_profiling": (C.c_int, [_VOIDP, C.c_int]),
+    "crf_take_kernel_time": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "crf_last_kernel_name": (C.c_char_p, [_VOIDP]),
+    "crf_synth_box_member": (C.c_int, [_VOIDP, _VOIDP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_uint64, _VOIDP]),
+}
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("CORRFIELD_LIBRARY", _HERE / "libcorrfield.so"))
+
+
+def load_library() -> C.CDLL:
+    """Loads the in-tree libcorrfield.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} not found: build it with `make -C correrender_amd/csrc` (or __graft_entry__.build()). "
+            "correrender_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib

@@ -1,0 +1,423 @@
+// api.cpp -- the C ABI of libcorrfield.so (include/corrfield.h) over the gfx950 kernels.
+//
+// Host-side responsibilities, mirroring what CorrelationCalculator::calculateCpu does around its hot loop
+// (reference: src/Calculators/CorrelationCalculator.cpp:781-866): hold the member volumes (resident in HBM), obtain
+// the reference vector, pick the estimator, launch, hand back xs*ys*zs floats.  No CPU fallback exists: without a
+// gfx950 device every entry point fails.
+#include "../../include/corrfield.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "crf_internal.h"
+
+namespace {
+thread_local std::string g_create_error;
+
+std::string fmt(const char* f, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+}  // namespace
+
+struct crf_context {
+    int device = -1;
+    hipStream_t stream = nullptr;  // the context's own stream (used when the caller passes none)
+    std::string err;
+    int xs = 0, ys = 0, zs = 0, cs = 0;
+    size_t num_voxels = 0;
+    // members
+    void* owned_block = nullptr;  // one allocation holding every uploaded member (stride owned_stride floats)
+    size_t owned_stride = 0;
+    std::vector<const float*> members;  // cs device pointers (owned or borrowed)
+    const float** d_member_table = nullptr;
+    int max_vpt = 1;
+    // scratch
+    float* d_ref = nullptr;    // cs reference values
+    float* d_prep = nullptr;   // crf::kPrepBytes
+    float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
+    uint32_t* d_minmax = nullptr;
+    bool minmax_valid = false;
+    float min_v = 0.f, max_v = 0.f;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::string last_kernel;
+};
+
+namespace {
+
+int fail(crf_context* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define CRF_HIP(ctx, call)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(ctx, CRF_ERR_DEVICE, fmt("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                                 __LINE__));                                                   \
+    } while (0)
+
+int bind_device(crf_context* c) {
+    CRF_HIP(c, hipSetDevice(c->device));
+    return CRF_OK;
+}
+
+void release_members(crf_context* c) {
+    if (c->owned_block) (void)hipFree(c->owned_block);
+    c->owned_block = nullptr;
+    c->members.clear();
+    c->minmax_valid = false;
+}
+
+int alignment_vpt(const void* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return (a & 15u) == 0 ? 4 : ((a & 7u) == 0 ? 2 : 1);
+}
+
+int install_member_table(crf_context* c) {
+    int vpt = 4;
+    for (const float* p : c->members) vpt = std::min(vpt, alignment_vpt(p));
+    c->max_vpt = vpt;
+    CRF_HIP(c, hipMemcpyAsync(c->d_member_table, c->members.data(), sizeof(float*) * size_t(c->cs),
+                              hipMemcpyHostToDevice, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    c->minmax_valid = false;
+    return CRF_OK;
+}
+
+int check_ready(crf_context* c) {
+    if (!c) return CRF_ERR_ARGUMENT;
+    if (c->cs <= 0 || c->num_voxels == 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    if (int(c->members.size()) != c->cs) return fail(c, CRF_ERR_STATE, "no member volumes uploaded or bound");
+    return CRF_OK;
+}
+
+hipEvent_t take_event(crf_context* c) {
+    if (!c->ev_free.empty()) {
+        hipEvent_t e = c->ev_free.back();
+        c->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crf_abi_version(void) { return 1; }
+
+const char* crf_last_error(const crf_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int crf_create(int device_ordinal, crf_context** out_ctx) {
+    if (!out_ctx) return CRF_ERR_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = fmt("no HIP device available (%s); libcorrfield has no CPU fallback",
+                             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return CRF_ERR_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) {
+        g_create_error = fmt("device ordinal %d out of range [0,%d)", device_ordinal, count);
+        return CRF_ERR_ARGUMENT;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) {
+        g_create_error = fmt("hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return CRF_ERR_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = fmt("device %d is %s; libcorrfield is built for gfx950 (MI355X) only", device_ordinal,
+                             prop.gcnArchName);
+        return CRF_ERR_DEVICE;
+    }
+    auto* c = new crf_context();
+    c->device = device_ordinal;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = fmt("%s: %s", what, hipGetErrorString(err));
+        crf_destroy(c);
+        return CRF_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    if ((e = hipMalloc(&c->d_prep, crf::kPrepBytes)) != hipSuccess) return bail("hipMalloc(prep)", e);
+    if ((e = hipMalloc(&c->d_minmax, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(minmax)", e);
+    *out_ctx = c;
+    return CRF_OK;
+}
+
+void crf_destroy(crf_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release_members(c);
+    if (c->d_member_table) (void)hipFree(c->d_member_table);
+    if (c->d_ref) (void)hipFree(c->d_ref);
+    if (c->d_prep) (void)hipFree(c->d_prep);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_minmax) (void)hipFree(c->d_minmax);
+    for (auto& p : c->ev_pending) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
+    if (!c) return CRF_ERR_ARGUMENT;
+    if (xs <= 0 || ys <= 0 || zs <= 0 || cs <= 0)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("invalid grid %dx%dx%d with %d members", xs, ys, zs, cs));
+    const size_t n = size_t(xs) * size_t(ys) * size_t(zs);
+    if (n * sizeof(float) > (size_t(1) << 32))
+        return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) larger than 4 GiB is not supported; shard it");
+    if (int r = bind_device(c)) return r;
+    release_members(c);
+    if (c->d_member_table) (void)hipFree(c->d_member_table);
+    if (c->d_ref) (void)hipFree(c->d_ref);
+    if (c->d_out) (void)hipFree(c->d_out);
+    c->d_member_table = nullptr;
+    c->d_ref = nullptr;
+    c->d_out = nullptr;
+    c->xs = xs;
+    c->ys = ys;
+    c->zs = zs;
+    c->cs = cs;
+    c->num_voxels = n;
+    CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_member_table), sizeof(float*) * size_t(cs)));
+    CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ref), sizeof(float) * size_t(cs)));
+    return CRF_OK;
+}
+
+int crf_upload_members(crf_context* c, const float* const* host_members) {
+    if (!c || !host_members) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    for (int i = 0; i < c->cs; i++)
+        if (!host_members[i]) return fail(c, CRF_ERR_ARGUMENT, fmt("member %d is a null pointer", i));
+    if (int r = bind_device(c)) return r;
+    release_members(c);
+    // Member stride: volume size rounded up to 256 B so every member starts 256-B aligned (wide vector loads).
+    const size_t stride = (c->num_voxels + 63) & ~size_t(63);
+    c->owned_stride = stride;
+    CRF_HIP(c, hipMalloc(&c->owned_block, stride * sizeof(float) * size_t(c->cs)));
+    c->members.resize(size_t(c->cs));
+    for (int i = 0; i < c->cs; i++) {
+        float* dst = static_cast<float*>(c->owned_block) + stride * size_t(i);
+        c->members[size_t(i)] = dst;
+        CRF_HIP(c, hipMemcpyAsync(dst, host_members[i], c->num_voxels * sizeof(float), hipMemcpyHostToDevice,
+                                  c->stream));
+    }
+    return install_member_table(c);
+}
+
+int crf_bind_members_device(crf_context* c, const void* const* device_members) {
+    if (!c || !device_members) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    for (int i = 0; i < c->cs; i++)
+        if (!device_members[i]) return fail(c, CRF_ERR_ARGUMENT, fmt("member %d is a null pointer", i));
+    if (int r = bind_device(c)) return r;
+    release_members(c);
+    c->members.resize(size_t(c->cs));
+    for (int i = 0; i < c->cs; i++) c->members[size_t(i)] = static_cast<const float*>(device_members[i]);
+    return install_member_table(c);
+}
+
+int crf_member_minmax(crf_context* c, float* out_min, float* out_max) {
+    if (int r = check_ready(c)) return r;
+    if (!out_min || !out_max) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (!c->minmax_valid) {
+        if (int r = bind_device(c)) return r;
+        CRF_HIP(c, crf::launch_minmax(c->d_member_table, c->cs, c->num_voxels, c->d_minmax, c->stream));
+        uint32_t keys[2];
+        CRF_HIP(c, hipMemcpyAsync(keys, c->d_minmax, sizeof keys, hipMemcpyDeviceToHost, c->stream));
+        CRF_HIP(c, hipStreamSynchronize(c->stream));
+        c->min_v = crf::minmax_key_to_float(keys[0]);
+        c->max_v = crf::minmax_key_to_float(keys[1]);
+        c->minmax_valid = true;
+    }
+    *out_min = c->min_v;
+    *out_max = c->max_v;
+    return CRF_OK;
+}
+
+static int ref_voxel(crf_context* c, int x, int y, int z, size_t* voxel) {
+    if (x < 0 || y < 0 || z < 0 || x >= c->xs || y >= c->ys || z >= c->zs)
+        return fail(c, CRF_ERR_ARGUMENT,
+                    fmt("reference point (%d,%d,%d) outside the local grid %dx%dx%d", x, y, z, c->xs, c->ys, c->zs));
+    *voxel = (size_t(z) * size_t(c->ys) + size_t(y)) * size_t(c->xs) + size_t(x);  // IDXS, DataSet.hpp:37
+    return CRF_OK;
+}
+
+int crf_gather_reference_device(crf_context* c, int x, int y, int z, void* device_out, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!device_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    size_t voxel;
+    if (int r = ref_voxel(c, x, y, z, &voxel)) return r;
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    CRF_HIP(c, crf::launch_gather_reference(c->d_member_table, c->cs, voxel, static_cast<float*>(device_out), s));
+    return CRF_OK;
+}
+
+int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
+    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (int r = crf_gather_reference_device(c, x, y, z, c ? c->d_ref : nullptr, nullptr)) return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_ref, sizeof(float) * size_t(c->cs), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
+int crf_compute_device(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                       void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!p || !device_out) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (p->measure < CRF_PEARSON || p->measure > CRF_KMI_CC)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("unknown measure %d", p->measure));
+    for (int v : p->reserved)
+        if (v != 0) return fail(c, CRF_ERR_ARGUMENT, "crf_params.reserved must be zero");
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    float* out = static_cast<float*>(device_out);
+
+    // 1. reference vector -> device (CorrelationCalculator.cpp:802-818)
+    const float* d_ref = static_cast<const float*>(device_reference_values);
+    if (!d_ref) {
+        if (p->reference_values) {
+            CRF_HIP(c, hipMemcpyAsync(c->d_ref, p->reference_values, sizeof(float) * size_t(c->cs),
+                                      hipMemcpyHostToDevice, s));
+        } else {
+            size_t voxel;
+            if (int r = ref_voxel(c, p->ref_x, p->ref_y, p->ref_z, &voxel)) return r;
+            CRF_HIP(c, crf::launch_gather_reference(c->d_member_table, c->cs, voxel, c->d_ref, s));
+        }
+        d_ref = c->d_ref;
+    }
+
+    // 2. estimator
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = take_event(c);
+        e1 = take_event(c);
+    }
+    const int vpt = std::min(c->max_vpt, alignment_vpt(out));
+    crf::LaunchInfo info;
+    hipError_t e = hipSuccess;
+    switch (p->measure) {
+        case CRF_PEARSON:
+            e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, d_ref, c->d_prep, out, s, e0, e1,
+                                    &info);
+            break;
+        case CRF_SPEARMAN:
+            if (c->cs > crf::kMaxSortMembers)
+                return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
+            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, d_ref, c->d_prep, out, s, e0, e1, &info);
+            break;
+        case CRF_KENDALL:
+            if (c->cs > crf::kMaxSortMembers)
+                return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
+            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, d_ref, c->d_prep, out, s, e0, e1, &info);
+            break;
+        case CRF_MI_BINNED:
+        case CRF_BINNED_MI_CC: {
+            if (p->num_bins < 1 || p->num_bins > 255)
+                return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
+            if (c->cs > crf::kMaxSortMembers)
+                return fail(c, CRF_ERR_UNSUPPORTED, fmt("binned MI supports at most %d members", crf::kMaxSortMembers));
+            crf::BinnedArgs a{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
+                              p->measure == CRF_BINNED_MI_CC};
+            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_prep, out, s, e0, e1,
+                                      &info);
+            break;
+        }
+        case CRF_MI_KRASKOV:
+        case CRF_KMI_CC: {
+            if (p->k < 1) return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be >= 1", p->k));
+            if (c->cs > crf::kMaxSortMembers)
+                return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kraskov MI supports at most %d members", crf::kMaxSortMembers));
+            const int est = p->kraskov_estimator_index == 2 ? 2 : 1;  // clamp as CorrelationCalculator.cpp:765
+            crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC};
+            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_prep, out, s, e0, e1,
+                                       &info);
+            break;
+        }
+    }
+    c->last_kernel = info.kernel_name ? info.kernel_name : "";
+    if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+    if (e == hipErrorNotSupported)
+        return fail(c, CRF_ERR_UNSUPPORTED, fmt("measure %d is not implemented by this build", p->measure));
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
+int crf_compute(crf_context* c, const crf_params* p, float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (int r = bind_device(c)) return r;
+    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
+    if (int r = crf_compute_device(c, p, nullptr, c->d_out, nullptr)) return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_out, c->num_voxels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
+int crf_set_profiling(crf_context* c, int enabled) {
+    if (!c) return CRF_ERR_ARGUMENT;
+    c->profiling = enabled != 0;
+    return CRF_OK;
+}
+
+int crf_take_kernel_time(crf_context* c, double* out_ms_sum, int* out_launches) {
+    if (!c || !out_ms_sum || !out_launches) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (int r = bind_device(c)) return r;
+    double sum = 0.0;
+    int n = 0;
+    for (auto& p : c->ev_pending) {
+        CRF_HIP(c, hipEventSynchronize(p.second));
+        float ms = 0.f;
+        CRF_HIP(c, hipEventElapsedTime(&ms, p.first, p.second));
+        sum += double(ms);
+        n++;
+        c->ev_free.push_back(p.first);
+        c->ev_free.push_back(p.second);
+    }
+    c->ev_pending.clear();
+    *out_ms_sum = sum;
+    *out_launches = n;
+    return CRF_OK;
+}
+
+const char* crf_last_kernel_name(const crf_context* c) { return c ? c->last_kernel.c_str() : ""; }
+
+int crf_synth_box_member(crf_context* c, void* device_out, int xs, int ys, int zs_local, int z_begin, int zs_global,
+                         int member, int cs, uint64_t seed, void* stream) {
+    if (!c || !device_out) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (xs <= 0 || ys <= 0 || zs_local <= 0 || zs_global <= 0 || z_begin < 0 || member < 0 || member >= cs)
+        return fail(c, CRF_ERR_ARGUMENT, "invalid synthetic volume description");
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    CRF_HIP(c, crf::launch_synth_box_member(static_cast<float*>(device_out), xs, ys, zs_local, z_begin, zs_global,
+                                            member, cs, seed, s));
+    return CRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// crf_internal.h -- declarations shared by the C-ABI (api.cpp) and the gfx950 kernel translation units.
+// Everything here is internal to libcorrfield.so; the public surface is include/corrfield.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace crf {
+
+// Largest member count the register-resident kernels are instantiated for; above it the streaming
+// (re-reading) variants run.
+constexpr int kMaxRegisterMembers = 256;
+// Largest member count supported at all by the sort-based estimators (LDS / register budgets).
+constexpr int kMaxSortMembers = 256;
+// Prepared reference-derived table: floats (see each kernels_*.hip for its layout).
+constexpr size_t kPrepBytes = 64 * 1024;
+
+struct LaunchInfo {
+    const char* kernel_name = "";  // dominant per-voxel kernel (for rocprof row matching)
+};
+
+// ---- kernels_common.hip -----------------------------------------------------------------------------------
+hipError_t launch_gather_reference(const float* const* d_members, int cs, size_t voxel, float* d_out, hipStream_t s);
+hipError_t launch_minmax(const float* const* d_members, int cs, size_t num_voxels, uint32_t* d_keys /*[2]*/,
+                         hipStream_t s);
+float minmax_key_to_float(uint32_t key);
+hipError_t launch_synth_box_member(float* d_out, int xs, int ys, int zs_local, int z_begin, int zs_global, int c,
+                                   int cs, uint64_t seed, hipStream_t s);
+
+// ---- kernels_pearson.hip ----------------------------------------------------------------------------------
+// d_ref: cs reference values on the device.  d_prep: scratch of kPrepBytes.  Writes num_voxels floats to d_out.
+// max_vpt: widest per-lane vector (1, 2 or 4 floats) the member/output pointers are aligned for.
+hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const float* d_ref,
+                          float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                          LaunchInfo* info);
+hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s);
+
+// ---- kernels_rank.hip (Spearman, Kendall) ---------------------------------------------------------------
+hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                           LaunchInfo* info);
+hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                          float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                          LaunchInfo* info);
+
+// ---- kernels_mi.hip (binned, Kraskov) -------------------------------------------------------------------
+struct BinnedArgs {
+    int num_bins;
+    float min_ref, max_ref, min_query, max_query;
+    bool to_cc;
+};
+hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                            const BinnedArgs& a, float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                            hipEvent_t ev_end, LaunchInfo* info);
+struct KraskovArgs {
+    int k;
+    int estimator;  // 1 or 2
+    bool to_cc;
+};
+hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                             const KraskovArgs& a, float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                             hipEvent_t ev_end, LaunchInfo* info);
+
+}  // namespace crf

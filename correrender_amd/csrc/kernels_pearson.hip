@@ -1,0 +1,265 @@
+// kernels_pearson.hip -- Pearson correlation field on gfx950.
+//
+// Semantics: computePearson2<float>(referenceValues, fields, cs, voxel) of the reference
+// (src/Calculators/Correlation.cpp:100-133, selected by FORMULA_2_FLOAT at CorrelationCalculator.cpp:887-893),
+// reproduced operation for operation in fp32 with contraction off (built with -ffp-contract=off) so that results
+// are bit-identical to the reference's x86-64 build (no FMA: CMakeLists.txt:34-36 sets no -march):
+//     pass 1   meanY += invN * y_e                         (e = 0..cs-1, sequential)
+//     pass 2   varY  += (invNm1 * (y_e - meanY)) * (y_e - meanY)
+//     pass 3   r     += (invNm1 * ((x_e - meanX) / sdX)) * ((y_e - meanY) / sdY)
+// Every reference-only term -- meanX, sdX and a_e = invNm1 * ((x_e - meanX) / sdX) -- is voxel independent and is
+// computed once by pearson_prep_kernel with the same sequential fp32 arithmetic; the per-voxel kernel then needs
+// only the cs a_e values (scalar loads -> SGPRs).
+//
+// Data movement (the bound): each voxel reads its cs member values exactly once from HBM (4*cs bytes) and writes
+// 4 bytes.  One lane owns VPT consecutive voxels and keeps all cs values in VGPRs across the three passes; a wave
+// load instruction covers 64*VPT consecutive floats of ONE member volume (256 B / 512 B / 1 KiB contiguous), all
+// cs loads of a wave are issued back to back before the first use, so a wave has cs*256*VPT bytes in flight.
+// No LDS, no MFMA: ~4 flop/byte, HBM-read bound.
+#include "crf_internal.h"
+#include <cstdlib>
+
+namespace crf {
+
+// ---------------------------------------------------------------------------------------------------------
+// Reference-side preparation: one wave.  d_prep[e] = a_e for e < cs.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pearson_prep_kernel(const float* __restrict__ ref, int cs,
+                                                          float* __restrict__ prep) {
+    __shared__ float sh[2];
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    if (threadIdx.x == 0) {
+        float meanX = 0.0f;
+        for (int e = 0; e < cs; e++) meanX += invN * ref[e];
+        float varX = 0.0f;
+        for (int e = 0; e < cs; e++) {
+            const float d = ref[e] - meanX;
+            varX += invNm1 * d * d;
+        }
+        sh[0] = meanX;
+        sh[1] = sqrtf(varX);
+    }
+    __syncthreads();
+    const float meanX = sh[0], sdX = sh[1];
+    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = invNm1 * ((ref[e] - meanX) / sdX);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-voxel kernel, members resident in registers.
+//   CS_PAD  compile-time upper bound of cs (loops fully unrolled to it); EXACT: cs == CS_PAD, no guards.
+//   VPT     voxels per lane (1, 2 or 4) = width of each global load in dwords.
+// ---------------------------------------------------------------------------------------------------------
+template <int VPT>
+struct VecT;
+template <>
+struct VecT<1> {
+    using type = float;
+};
+template <>
+struct VecT<2> {
+    using type = float2;
+};
+template <>
+struct VecT<4> {
+    using type = float4;
+};
+
+template <int VPT>
+__device__ __forceinline__ void load_vec(const float* p, float (&dst)[VPT]) {
+    using V = typename VecT<VPT>::type;
+    const V v = *reinterpret_cast<const V*>(p);
+    __builtin_memcpy(dst, &v, sizeof(V));
+}
+template <int VPT>
+__device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
+    using V = typename VecT<VPT>::type;
+    V v;
+    __builtin_memcpy(&v, src, sizeof(V));
+    *reinterpret_cast<V*>(p) = v;
+}
+
+template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
+                                                                     const float* __restrict__ prep,
+                                                                     float* __restrict__ out, size_t voxel_offset,
+                                                                     int cs) {
+    const size_t v0 = voxel_offset + (size_t(blockIdx.x) * 256 + threadIdx.x) * VPT;
+    float y[CS_PAD][VPT];
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        if (EXACT || e < cs) load_vec<VPT>(members[e] + v0, y[e]);
+    }
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+
+    float meanY[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; v++) meanY[v] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        if (EXACT || e < cs) {
+#pragma unroll
+            for (int v = 0; v < VPT; v++) meanY[v] += invN * y[e][v];
+        }
+    }
+    float varY[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; v++) varY[v] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        if (EXACT || e < cs) {
+#pragma unroll
+            for (int v = 0; v < VPT; v++) {
+                const float d = y[e][v] - meanY[v];
+                y[e][v] = d;  // (y_e - meanY) is needed again, bit-identically, by pass 3
+                varY[v] += invNm1 * d * d;
+            }
+        }
+    }
+    float r[VPT];
+    float sdY[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; v++) {
+        sdY[v] = sqrtf(varY[v]);
+        r[v] = 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        if (EXACT || e < cs) {
+            const float a = prep[e];
+#pragma unroll
+            for (int v = 0; v < VPT; v++) r[v] += a * (y[e][v] / sdY[v]);
+        }
+    }
+    store_vec<VPT>(out + v0, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming fallback for any cs (three passes re-reading the members; the second and third mostly hit L2/MALL) and
+// for the ragged tail of the grid.  One voxel per lane, bounds-checked.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pearson_stream_kernel(const float* const* __restrict__ members,
+                                                             const float* __restrict__ prep,
+                                                             float* __restrict__ out, size_t voxel_offset,
+                                                             size_t voxel_end, int cs) {
+    const size_t v0 = voxel_offset + size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (v0 >= voxel_end) return;
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanY = 0.0f;
+    for (int e = 0; e < cs; e++) meanY += invN * members[e][v0];
+    float varY = 0.0f;
+    for (int e = 0; e < cs; e++) {
+        const float d = members[e][v0] - meanY;
+        varY += invNm1 * d * d;
+    }
+    const float sdY = sqrtf(varY);
+    float r = 0.0f;
+    for (int e = 0; e < cs; e++) r += prep[e] * ((members[e][v0] - meanY) / sdY);
+    out[v0] = r;
+}
+
+__global__ void fill_kernel(float* __restrict__ out, size_t n, float value) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = value;
+}
+
+namespace {
+
+template <int CS_PAD, int VPT>
+void launch_reg(const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, int cs,
+                hipStream_t s) {
+    // occupancy request: data registers are CS_PAD*VPT per lane; ask for the waves/SIMD that budget allows.
+    constexpr int kData = CS_PAD * VPT;
+    constexpr int kMinWaves = kData <= 64 ? 4 : (kData <= 128 ? 2 : 1);
+    if (cs == CS_PAD) {
+        hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, true, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0, s,
+                           d_members, d_prep, d_out, size_t(0), cs);
+    } else {
+        hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, false, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0,
+                           s, d_members, d_prep, d_out, size_t(0), cs);
+    }
+}
+
+template <int CS_PAD>
+void launch_reg_vpt(int vpt, const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, int cs,
+                    hipStream_t s) {
+    if constexpr (CS_PAD * 4 <= 256) {
+        if (vpt == 4) return launch_reg<CS_PAD, 4>(d_members, d_prep, d_out, blocks, cs, s);
+    }
+    if constexpr (CS_PAD * 2 <= 256) {
+        if (vpt >= 2) return launch_reg<CS_PAD, 2>(d_members, d_prep, d_out, blocks, cs, s);
+    }
+    return launch_reg<CS_PAD, 1>(d_members, d_prep, d_out, blocks, cs, s);
+}
+
+int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+
+}  // namespace
+
+hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_out, n, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const float* d_ref,
+                          float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                          LaunchInfo* info) {
+    if (cs == 1) {  // CorrelationCalculator.cpp:882-885
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        if (info) info->kernel_name = "fill_kernel";
+        return e;
+    }
+    hipLaunchKernelGGL(pearson_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, d_prep);
+
+    size_t covered = 0;
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    if (cs <= kMaxRegisterMembers) {
+        const int cs_pad = cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 48 ? 48 : cs <= 64 ? 64 : cs <= 96 ? 96
+                         : cs <= 128 ? 128 : cs <= 192 ? 192 : 256;
+        // voxels per lane: default keeps cs_pad*vpt <= 128 data VGPRs (>= 2-3 waves/SIMD); CRF_PEARSON_VPT overrides
+        // for tuning experiments.
+        int vpt = cs_pad <= 32 ? 4 : (cs_pad <= 64 ? 2 : 1);
+        vpt = env_int("CRF_PEARSON_VPT", vpt);
+        if (vpt > max_vpt) vpt = max_vpt;
+        while (vpt > 1 && cs_pad * vpt > 256) vpt >>= 1;
+        if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 1;
+        const size_t per_block = size_t(256) * vpt;
+        const size_t blocks = num_voxels / per_block;
+        covered = blocks * per_block;
+        if (blocks > 0) {
+            switch (cs_pad) {
+                case 16: launch_reg_vpt<16>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 32: launch_reg_vpt<32>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 48: launch_reg_vpt<48>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 64: launch_reg_vpt<64>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 96: launch_reg_vpt<96>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 128: launch_reg_vpt<128>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                default: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+            }
+        }
+        if (info) info->kernel_name = "pearson_reg_kernel";
+    } else {
+        if (info) info->kernel_name = "pearson_stream_kernel";
+    }
+    if (covered < num_voxels) {
+        const size_t rest = num_voxels - covered;
+        hipLaunchKernelGGL(pearson_stream_kernel, dim3(unsigned((rest + 255) / 256)), dim3(256), 0, s, d_members,
+                           d_prep, d_out, covered, num_voxels, cs);
+    }
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    return hipGetLastError();
+}
+
+}  // namespace crf

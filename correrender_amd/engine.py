@@ -1,0 +1,192 @@
+"""Python host layer over the C ABI: one `CorrField` = one crf_context = one GPU (one process per GPU).
+
+Mirrors the state a reference `CorrelationCalculator` holds (src/Calculators/CorrelationCalculator.hpp:200-213):
+measure, reference point, k, estimator index, number of bins.  Tensors are torch CUDA tensors (device memory and
+streams only -- torch is plumbing here) or numpy arrays on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ._lib import CorrFieldError, CrfParams, load_library
+
+
+class Measure(enum.IntEnum):
+    """enum class CorrelationMeasureType (src/Calculators/CorrelationDefines.hpp:41-45)."""
+    PEARSON = 0
+    SPEARMAN = 1
+    KENDALL = 2
+    MUTUAL_INFORMATION_BINNED = 3
+    MUTUAL_INFORMATION_KRASKOV = 4
+    BINNED_MI_CORRELATION_COEFFICIENT = 5
+    KMI_CORRELATION_COEFFICIENT = 6
+
+
+# CORRELATION_MEASURE_TYPE_IDS (CorrelationDefines.hpp:54-57)
+MEASURE_IDS = ["pearson", "spearman", "kendall", "mi_binned", "mi_kraskov",
+               "binned_mi_correlation_coefficient", "kmi_correlation_coefficient"]
+
+
+def default_kraskov_k(cs: int) -> int:
+    """k = max(iceil(3*cs, 100), 1) (CorrelationCalculator.cpp:592-598)."""
+    return max(-(-3 * cs // 100), 1)
+
+
+class CorrField:
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        ctx = C.c_void_p()
+        rc = self._lib.crf_create(int(device), C.byref(ctx))
+        if rc != 0:
+            raise CorrFieldError(rc, (self._lib.crf_last_error(None) or b"").decode())
+        self._ctx = ctx
+        self.device = int(device)
+        self.grid = None
+        self.cs = 0
+        self._keepalive = None
+
+    # -- plumbing -----------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CorrFieldError(rc, (self._lib.crf_last_error(self._ctx) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.crf_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def num_voxels(self) -> int:
+        xs, ys, zs = self.grid
+        return xs * ys * zs
+
+    # -- ensemble -----------------------------------------------------------------------------------------
+    def set_grid(self, xs: int, ys: int, zs: int, cs: int):
+        self._check(self._lib.crf_set_grid(self._ctx, xs, ys, zs, cs))
+        self.grid = (xs, ys, zs)
+        self.cs = cs
+        self._keepalive = None
+
+    def upload_members(self, members: Sequence[np.ndarray]):
+        """members: cs host arrays of zs*ys*xs float32 (any shape, C-contiguous, x fastest)."""
+        arrs = [np.ascontiguousarray(m, dtype=np.float32) for m in members]
+        if len(arrs) != self.cs or any(a.size != self.num_voxels for a in arrs):
+            raise ValueError("members do not match the grid declared with set_grid")
+        ptrs = (C.c_void_p * self.cs)(*[a.ctypes.data for a in arrs])
+        self._check(self._lib.crf_upload_members(self._ctx, ptrs))
+
+    def bind_members(self, members):
+        """members: cs torch CUDA float32 tensors (or one [cs, ...] tensor), each holding one volume; borrowed."""
+        tensors = [members[i] for i in range(self.cs)]
+        for t in tensors:
+            if not t.is_cuda or not t.is_contiguous() or t.numel() != self.num_voxels or t.element_size() != 4:
+                raise ValueError("each member must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
+        ptrs = (C.c_void_p * self.cs)(*[t.data_ptr() for t in tensors])
+        self._check(self._lib.crf_bind_members_device(self._ctx, ptrs))
+        self._keepalive = (members, tensors)
+
+    def member_minmax(self):
+        mn, mx = C.c_float(), C.c_float()
+        self._check(self._lib.crf_member_minmax(self._ctx, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    # -- reference vector ---------------------------------------------------------------------------------
+    def gather_reference(self, x: int, y: int, z: int) -> np.ndarray:
+        out = np.empty(self.cs, dtype=np.float32)
+        self._check(self._lib.crf_gather_reference(self._ctx, x, y, z, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def gather_reference_device(self, x: int, y: int, z: int, out, stream: int = 0):
+        self._check(self._lib.crf_gather_reference_device(self._ctx, x, y, z, C.c_void_p(out.data_ptr()),
+                                                          C.c_void_p(stream)))
+
+    # -- evaluation ---------------------------------------------------------------------------------------
+    def _params(self, measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                reference_values):
+        p = CrfParams()
+        p.measure = int(measure)
+        rx, ry, rz = ref if ref is not None else (0, 0, 0)
+        p.ref_x, p.ref_y, p.ref_z = int(rx), int(ry), int(rz)
+        p.k = int(k if k is not None else default_kraskov_k(self.cs))
+        p.kraskov_estimator_index = int(kraskov_estimator_index)
+        p.num_bins = int(num_bins)
+        if minmax_ref is not None:
+            p.min_ref, p.max_ref = float(minmax_ref[0]), float(minmax_ref[1])
+        if minmax_query is not None:
+            p.min_query, p.max_query = float(minmax_query[0]), float(minmax_query[1])
+        keep = None
+        if reference_values is not None:
+            keep = np.ascontiguousarray(reference_values, dtype=np.float32)
+            if keep.size != self.cs:
+                raise ValueError("reference_values must hold cs floats")
+            p.reference_values = keep.ctypes.data_as(C.POINTER(C.c_float))
+        return p, keep
+
+    def _binned_ranges(self, measure, minmax_ref, minmax_query):
+        if int(measure) in (Measure.MUTUAL_INFORMATION_BINNED, Measure.BINNED_MI_CORRELATION_COEFFICIENT):
+            if minmax_ref is None:
+                minmax_ref = self.member_minmax()      # SINGLE mode: CorrelationCalculator.cpp:822-829
+            if minmax_query is None:
+                minmax_query = minmax_ref              # :843-846
+        return minmax_ref, minmax_query
+
+    def compute(self, measure, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
+                minmax_query=None, reference_values=None) -> np.ndarray:
+        """Synchronous evaluation to a host array of shape (zs, ys, xs) -- calculateCpu(t, e, buffer)."""
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query)
+        p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                               reference_values)
+        xs, ys, zs = self.grid
+        out = np.empty((zs, ys, xs), dtype=np.float32)
+        self._check(self._lib.crf_compute(self._ctx, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))))
+        del keep
+        return out
+
+    def compute_device(self, measure, out, ref=None, *, device_reference=None, stream: int = 0, k=None,
+                       kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
+                       reference_values=None):
+        """Asynchronous, stream-ordered evaluation into a CUDA float32 tensor `out` of xs*ys*zs elements."""
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query)
+        p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                               reference_values)
+        if out.numel() != self.num_voxels or not out.is_cuda or not out.is_contiguous():
+            raise ValueError("out must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
+        dref = C.c_void_p(device_reference.data_ptr()) if device_reference is not None else C.c_void_p(0)
+        self._check(self._lib.crf_compute_device(self._ctx, C.byref(p), dref, C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(stream)))
+        if keep is not None:  # the H2D copy of a host reference vector is asynchronous: keep it alive
+            self._keep_ref = keep
+        return out
+
+    # -- instrumentation ----------------------------------------------------------------------------------
+    def set_profiling(self, enabled: bool):
+        self._check(self._lib.crf_set_profiling(self._ctx, 1 if enabled else 0))
+
+    def take_kernel_time(self):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self._lib.crf_take_kernel_time(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_kernel_name(self) -> str:
+        return (self._lib.crf_last_kernel_name(self._ctx) or b"").decode()
+
+    def synth_box_member(self, out, xs, ys, zs_local, z_begin, zs_global, c, cs, seed, stream: int = 0):
+        self._check(self._lib.crf_synth_box_member(self._ctx, C.c_void_p(out.data_ptr()), xs, ys, zs_local, z_begin,
+                                                   zs_global, c, cs, C.c_uint64(seed), C.c_void_p(stream)))

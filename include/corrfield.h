@@ -1,0 +1,128 @@
+/*
+ * corrfield.h -- C ABI of libcorrfield.so, the MI355X (gfx950) correlation-field engine.
+ *
+ * Drop-in boundary for ONE path of chrismile/Correrender: the per-voxel ensemble correlation estimators evaluated
+ * between one reference grid point and every voxel of a 3-D grid, i.e. what
+ *     void CorrelationCalculator::calculateCpu(int timeStepIdx, int ensembleIdx, float* buffer)
+ * (reference: src/Calculators/CorrelationCalculator.cpp:781-1154, declared src/Calculators/Calculator.hpp:123-124)
+ * computes.  The reference has no C ABI (calculators are compiled-in C++ classes registered as factories,
+ * src/Volume/VolumeData.cpp:198-232); these entry points are what a `Calculator` subclass living in the reference
+ * tree would bind to hand the hot loop to the GPU -- see INTEGRATION.md for that subclass and
+ * correrender_amd/csrc/host/ for this repo's mirror of the ICorrelationCalculator/VolumeData surface built on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types; every function returns 0 on success, non-zero on error
+ *     (the reference reports errors through sgl::Logfile::throwError, e.g. VolumeData.cpp:1217-1221; the adapter
+ *     maps a non-zero status + crf_last_error() onto that).
+ *   - single caller thread per context (the reference calls calculators from the render thread only,
+ *     VolumeData.cpp:1225,1469-1472); no re-entrancy.
+ *   - volumes are fp32, x fastest: voxel (x,y,z) at z*xs*ys + y*xs + x  (IDXS, src/Loaders/DataSet.hpp:37);
+ *     the ensemble is member-major SoA: one contiguous volume per member
+ *     (std::vector<const float*> fields, CorrelationCalculator.cpp:791-800).
+ *   - outputs are caller-owned: exactly xs*ys*zs floats are written, nothing is retained
+ *     (VolumeData.cpp:1222-1226 allocates the buffer and wraps it in a HostCacheEntry).
+ *   - There is NO CPU fallback: every compute entry point fails with CRF_ERR_DEVICE if no gfx950 device is usable.
+ */
+#ifndef CORRFIELD_H
+#define CORRFIELD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crf_context crf_context;
+
+/* Same order and meaning as enum class CorrelationMeasureType (src/Calculators/CorrelationDefines.hpp:41-45);
+ * the string ids are CORRELATION_MEASURE_TYPE_IDS (CorrelationDefines.hpp:54-57). */
+typedef enum crf_measure {
+    CRF_PEARSON = 0,                 /* "pearson"   computePearson2<float>, Correlation.cpp:100-133 */
+    CRF_SPEARMAN = 1,                /* "spearman"  computeRanks + computePearson2<float>, :277-303,:141-174 */
+    CRF_KENDALL = 2,                 /* "kendall"   computeKendall<int32_t> (tau-b), :423-455 */
+    CRF_MI_BINNED = 3,               /* "mi_binned" computeMutualInformationBinned<double>, MutualInformation.cpp:45-143 */
+    CRF_MI_KRASKOV = 4,              /* "mi_kraskov" computeMutualInformationKraskov[2]<double>, :399-509 */
+    CRF_BINNED_MI_CC = 5,            /* "binned_mi_correlation_coefficient"  sqrt(1-exp(-2 MI)), CorrelationCalculator.cpp:1071-1073 */
+    CRF_KMI_CC = 6                   /* "kmi_correlation_coefficient"        same map, :1130-1132 */
+} crf_measure;
+
+enum {
+    CRF_OK = 0,
+    CRF_ERR_ARGUMENT = 1,   /* bad pointer / size / enum */
+    CRF_ERR_STATE = 2,      /* grid or members not set */
+    CRF_ERR_DEVICE = 3,     /* HIP error or no usable gfx950 device */
+    CRF_ERR_UNSUPPORTED = 4 /* configuration outside what the kernels implement (message says which) */
+};
+
+/* One evaluation = the state CorrelationCalculator holds when calculateCpu runs
+ * (CorrelationCalculator.hpp:200-213 and ICorrelationCalculator members :120-140). */
+typedef struct crf_params {
+    int32_t measure;                 /* crf_measure */
+    int32_t ref_x, ref_y, ref_z;     /* referencePointIndex in LOCAL grid coordinates; used when reference_values==NULL */
+    int32_t k;                       /* kmi_neighbors (Kraskov); default max(ceil(3*cs/100),1), CorrelationCalculator.cpp:592-598 */
+    int32_t kraskov_estimator_index; /* 1 = KSG-1 (default), 2 = KSG-2 */
+    int32_t num_bins;                /* mi_bins, default 80 (CorrelationCalculator.hpp:209) */
+    float min_ref, max_ref;          /* binned MI: extrema used to normalise the reference vector (:820-833) */
+    float min_query, max_query;      /* binned MI: extrema used to normalise each voxel's vector (:834-846,:1061-1062) */
+    const float* reference_values;   /* HOST pointer to cs floats, or NULL.  Non-NULL = CorrelationFieldMode::SEPARATE
+                                        / time-lag (reference vector taken from another field, :804-813) or a vector
+                                        received from another rank. */
+    int32_t reserved[4];             /* must be 0 */
+} crf_params;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+/* Creates a context bound to HIP device `device_ordinal`.  Fails (CRF_ERR_DEVICE) when the device is absent or is
+ * not gfx950.  *out_ctx is set to NULL on failure; crf_last_error(NULL) then holds the message. */
+int crf_create(int device_ordinal, crf_context** out_ctx);
+void crf_destroy(crf_context* ctx);
+/* Last error message of this context (or of the calling thread's last failed crf_create when ctx==NULL). */
+const char* crf_last_error(const crf_context* ctx);
+/* ABI version of this header, bumped on incompatible change. */
+int crf_abi_version(void);
+
+/* ---- the ensemble (replaces the fields[] gather of CorrelationCalculator.cpp:791-800) --------------------- */
+/* Declares the LOCAL grid (a whole grid, or this process's z-slab of one) and member count; drops any members. */
+int crf_set_grid(crf_context* ctx, int xs, int ys, int zs, int cs);
+/* Copies cs host volumes (each xs*ys*zs floats) into HBM owned by the context (the role the reference's LRU
+ * field cache plays across reference-point moves, VolumeData.cpp:1202-1226). */
+int crf_upload_members(crf_context* ctx, const float* const* host_members);
+/* Uses cs caller-owned DEVICE volumes in place (borrowed until the next set_grid/upload/bind/destroy). */
+int crf_bind_members_device(crf_context* ctx, const void* const* device_members);
+/* min of per-member minima / max of per-member maxima over the local grid (CorrelationCalculator.cpp:822-829 on
+ * top of VolumeData::getMinMaxScalarFieldValue, VolumeData.cpp:1632-1670); computed on the device, cached until
+ * the members change. */
+int crf_member_minmax(crf_context* ctx, float* out_min, float* out_max);
+
+/* ---- reference vector (CorrelationCalculator.cpp:802,815-817) --------------------------------------------- */
+/* referenceValues[c] = member_c[IDXS(x,y,z)] -> cs floats to a host buffer (synchronous) ... */
+int crf_gather_reference(crf_context* ctx, int x, int y, int z, float* host_out);
+/* ... or to a device buffer, asynchronously on `stream` (a hipStream_t, NULL = the context's own stream). */
+int crf_gather_reference_device(crf_context* ctx, int x, int y, int z, void* device_out, void* stream);
+
+/* ---- evaluation (replaces the hot loop CorrelationCalculator.cpp:868-1142) ------------------------------- */
+/* Synchronous, host output: what calculateCpu(t, e, buffer) does.  host_out receives xs*ys*zs floats. */
+int crf_compute(crf_context* ctx, const crf_params* params, float* host_out);
+/* Asynchronous, device output, stream-ordered, no host synchronisation: the form the multi-GPU path and the
+ * benchmark use.  device_reference_values: DEVICE pointer to cs floats or NULL (then params->reference_values or
+ * the reference point are used).  device_out receives xs*ys*zs floats. */
+int crf_compute_device(crf_context* ctx, const crf_params* params, const void* device_reference_values,
+                       void* device_out, void* stream);
+
+/* ---- instrumentation --------------------------------------------------------------------------------------- */
+/* When enabled, every crf_compute* brackets its dominant (per-voxel) kernel with HIP events on the launch stream. */
+int crf_set_profiling(crf_context* ctx, int enabled);
+/* Sum of the recorded kernel durations (ms) and their count since the last call; synchronises the events.  Resets. */
+int crf_take_kernel_time(crf_context* ctx, double* out_ms_sum, int* out_launches);
+/* Name of the dominant kernel of the last compute (for matching rocprofv3 rows), valid until the next call. */
+const char* crf_last_kernel_name(const crf_context* ctx);
+/* Fills device memory with a deterministic synthetic "box ensemble" member volume (recipe of the
+ * reference's scripts/generate_synth_box_ensembles.py:57-136) for a z-slab [z_begin, z_begin+zs_local) of a global
+ * xs*ys*zs_global grid: member `c` of `cs`.  Benchmark/test input generation only; not on the timed path. */
+int crf_synth_box_member(crf_context* ctx, void* device_out, int xs, int ys, int zs_local, int z_begin, int zs_global,
+                         int c, int cs, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORRFIELD_H */

@@ -1,0 +1,30 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+if str(ROOT / "tests") not in sys.path:
+    sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One CorrField on cuda:0 for the whole GPU test session (a single process uses the card)."""
+    import correrender_amd as ca
+    eng = ca.CorrField(0)
+    yield eng
+    eng.close()

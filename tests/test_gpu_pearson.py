@@ -1,0 +1,97 @@
+"""GPU parity: Pearson through the C ABI vs the oracle (bit-exact: same fp32 operation order, no contraction)."""
+import numpy as np
+import pytest
+
+from correrender_amd import Measure, synth
+from parity import assert_bit_exact, bit_identical
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine, oracle, ens, ref_xyz):
+    cs, zs, ys, xs = ens.shape
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    got = engine.compute(Measure.PEARSON, ref_xyz)
+    x, y, z = ref_xyz
+    ref_values = ens[:, z, y, x].copy()
+    np.testing.assert_array_equal(engine.gather_reference(x, y, z), ref_values)
+    want = oracle.field(oracle_lib.PEARSON, ens, ref_values)
+    return got.reshape(-1), want
+
+
+@pytest.mark.parametrize("cs", [2, 3, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 130, 200, 256, 300])
+def test_pearson_member_counts(engine, oracle, cs):
+    # 20*12*9 = 2160 voxels: not a multiple of any block size -> exercises the ragged tail as well
+    ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
+    got, want = _run(engine, oracle, ens, (5, 6, 4))
+    assert_bit_exact(got, want, f"pearson cs={cs}")
+
+
+def test_pearson_config0_64cubed_16_members(engine, oracle):
+    """BASELINE.json configs[0]: 64^3 synthetic box ensemble, 16 members, Pearson."""
+    ens = synth.box_ensemble(64, 64, 64, 16)
+    for ref_xyz in [(32, 32, 32), (8, 8, 32)]:
+        got, want = _run(engine, oracle, ens, ref_xyz)
+        assert_bit_exact(got, want, f"pearson 64^3x16 ref={ref_xyz}")
+        assert np.isfinite(got).all()
+    # structure: voxels inside the first big box (lambda=1) correlate perfectly with a reference inside it
+    got3 = got.reshape(64, 64, 64)
+    assert got3[32, 8, 8] == pytest.approx(1.0, abs=1e-6)
+
+
+def test_pearson_edge_cases(engine, oracle):
+    rng = np.random.default_rng(7)
+    ens = rng.standard_normal((24, 4, 8, 16)).astype(np.float32)
+    ens[:, 0, 0, 1] = 3.25                 # zero variance -> 0/0 = NaN, no epsilon (Correlation.cpp:124-131)
+    ens[5, 0, 0, 2] = np.nan               # NaN propagates (no NaN test on the Pearson branch)
+    ens[7, 0, 0, 3] = np.inf
+    ens[:, 1, 1, 1] = ens[:, 2, 2, 2] * 1e-30   # tiny magnitudes (denormal intermediates)
+    ens[:, 1, 1, 2] = ens[:, 2, 2, 2] * 1e18    # large magnitudes
+    got, want = _run(engine, oracle, ens, (2, 2, 2))
+    assert_bit_exact(got, want, "pearson edge cases")
+    assert np.isnan(got.reshape(4, 8, 16)[0, 0, 1])
+    assert np.isnan(got.reshape(4, 8, 16)[0, 0, 2])
+
+
+def test_pearson_single_member_is_one(engine):
+    ens = synth.box_ensemble(8, 8, 4, 1)
+    engine.set_grid(8, 8, 4, 1)
+    engine.upload_members(ens)
+    got = engine.compute(Measure.PEARSON, (1, 1, 1))
+    assert (got == 1.0).all()      # CorrelationCalculator.cpp:882-885
+
+
+def test_pearson_separate_reference_vector(engine, oracle):
+    """CorrelationFieldMode::SEPARATE: reference vector supplied by the caller (CorrelationCalculator.cpp:804-813)."""
+    ens = synth.box_ensemble(16, 16, 8, 32, seed=11)
+    other = synth.box_ensemble(16, 16, 8, 32, seed=12)
+    ref_values = other[:, 4, 8, 8].copy()
+    engine.set_grid(16, 16, 8, 32)
+    engine.upload_members(ens)
+    got = engine.compute(Measure.PEARSON, reference_values=ref_values)
+    want = oracle.field(oracle_lib.PEARSON, ens, ref_values)
+    assert_bit_exact(got, want, "pearson separate reference")
+
+
+def test_pearson_device_path_matches_host_path(engine, oracle):
+    import torch
+    ens = synth.box_ensemble(32, 32, 16, 64, seed=5)
+    cs, zs, ys, xs = ens.shape
+    dev = torch.from_numpy(ens).cuda()
+    engine.set_grid(xs, ys, zs, cs)
+    engine.bind_members(dev)
+    out = torch.empty(zs * ys * xs, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.compute_device(Measure.PEARSON, out, (16, 16, 8), stream=stream)
+    torch.cuda.synchronize()
+    want = oracle.field(oracle_lib.PEARSON, ens, ens[:, 8, 16, 16].copy())
+    assert_bit_exact(out.cpu().numpy(), want, "pearson device path")
+    # device-resident reference vector (the multi-GPU broadcast form)
+    dref = torch.from_numpy(ens[:, 3, 2, 1].copy()).cuda()
+    engine.compute_device(Measure.PEARSON, out, device_reference=dref, stream=stream)
+    torch.cuda.synchronize()
+    want = oracle.field(oracle_lib.PEARSON, ens, ens[:, 3, 2, 1].copy())
+    assert_bit_exact(out.cpu().numpy(), want, "pearson device reference")
+    assert bit_identical(out.cpu().numpy(), want).all()
