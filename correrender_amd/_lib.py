@@ -70,6 +70,13 @@ def load_library() -> C.CDLL:
         raise FileNotFoundError(
             f"{path} not found: build it with `make -C correrender_amd/csrc` (or __graft_entry__.build()). "
             "correrender_amd has no CPU fallback.")
+    # torch wheels bundle their own HIP runtime (libamdhip64); it must be the one the process loads FIRST, otherwise a
+    # later `import torch` finds a second, already-initialised runtime and reports "No HIP GPUs are available".
+    # torch is this package's device-memory / stream / torch.distributed plumbing, so import it up front.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(path))
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge

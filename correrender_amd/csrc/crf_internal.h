@@ -11,7 +11,7 @@ namespace crf {
 // (re-reading) variants run.
 constexpr int kMaxRegisterMembers = 256;
 // Largest member count supported at all by the sort-based estimators (LDS / register budgets).
-constexpr int kMaxSortMembers = 256;
+constexpr int kMaxSortMembers = 128;
 // Prepared reference-derived table: floats (see each kernels_*.hip for its layout).
 constexpr size_t kPrepBytes = 64 * 1024;
 

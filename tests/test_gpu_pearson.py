@@ -44,7 +44,8 @@ def test_pearson_config0_64cubed_16_members(engine, oracle):
 def test_pearson_edge_cases(engine, oracle):
     rng = np.random.default_rng(7)
     ens = rng.standard_normal((24, 4, 8, 16)).astype(np.float32)
-    ens[:, 0, 0, 1] = 3.25                 # zero variance -> 0/0 = NaN, no epsilon (Correlation.cpp:124-131)
+    ens[:, 0, 0, 1] = 0.0                  # zero variance -> 0/0 = NaN, no epsilon (Correlation.cpp:124-131)
+    ens[:, 0, 0, 4] = 3.25                 # constant but the fp32 mean is inexact: whatever the reference gives
     ens[5, 0, 0, 2] = np.nan               # NaN propagates (no NaN test on the Pearson branch)
     ens[7, 0, 0, 3] = np.inf
     ens[:, 1, 1, 1] = ens[:, 2, 2, 2] * 1e-30   # tiny magnitudes (denormal intermediates)

@@ -1,0 +1,95 @@
+"""GPU parity: Spearman and Kendall through the C ABI vs the oracle -- bit-exact (integer/ordering cores, exact
+fp32 tails)."""
+import numpy as np
+import pytest
+
+from correrender_amd import Measure, synth
+from parity import assert_bit_exact
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+MEASURES = [(Measure.SPEARMAN, oracle_lib.SPEARMAN), (Measure.KENDALL, oracle_lib.KENDALL)]
+
+
+def _check(engine, oracle, ens, ref_xyz, measure, omeasure, what, reference_values=None):
+    cs, zs, ys, xs = ens.shape
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    if reference_values is None:
+        x, y, z = ref_xyz
+        ref_values = ens[:, z, y, x].copy()
+        got = engine.compute(measure, ref_xyz)
+    else:
+        ref_values = reference_values
+        got = engine.compute(measure, reference_values=reference_values)
+    want = oracle.field(omeasure, ens, ref_values)
+    assert_bit_exact(got, want, what)
+    return got
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+@pytest.mark.parametrize("cs", [2, 3, 7, 16, 17, 32, 33, 50, 64, 65, 100, 128])
+def test_rank_member_counts(engine, oracle, measure, omeasure, cs):
+    ens = synth.box_ensemble(20, 12, 9, cs, seed=100 + cs)
+    _check(engine, oracle, ens, (5, 6, 4), measure, omeasure, f"{measure.name} cs={cs}")
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+def test_rank_ties_everywhere(engine, oracle, measure, omeasure):
+    """Heavily tied data (values rounded to a few levels): fractional ranks, tau-b tie terms, x-tie groups, the
+    reference's ignored joint ties."""
+    rng = np.random.default_rng(3)
+    for cs in (8, 24, 64, 100):
+        ens = np.round(rng.standard_normal((cs, 4, 8, 16)) * 1.5).astype(np.float32)
+        ens[:, 0, 0, 0] = 2.0                       # all-equal voxel: 0/0 -> NaN (Kendall), NaN (Spearman)
+        ens[:, 0, 0, 1] = np.arange(cs)             # strictly increasing
+        ens[:, 0, 0, 2] = -np.arange(cs)            # strictly decreasing
+        ens[:, 0, 0, 3] = np.where(np.arange(cs) % 2 == 0, 0.0, -0.0)   # +0 / -0 are equal
+        _check(engine, oracle, ens, (5, 3, 2), measure, omeasure, f"{measure.name} ties cs={cs}")
+        # reference vector with ties as well as one without
+        _check(engine, oracle, ens, None, measure, omeasure, f"{measure.name} ties/ramp-ref cs={cs}",
+               reference_values=np.arange(cs, dtype=np.float32))
+        # constant reference vector: n0 - n1 = 0 -> division by zero -> NaN or +-inf exactly as the reference
+        _check(engine, oracle, ens, None, measure, omeasure, f"{measure.name} ties/const-ref cs={cs}",
+               reference_values=np.full(cs, 1.5, np.float32))
+
+
+def test_kendall_known_answer(engine):
+    """x=[1,1,2,2,3,3,4,4], y=[1,2,2,3,3,3,5,4] -> 0.833333254 (=20/24 via two sqrtf; SciPy's
+    tau-b gives 0.875 because the reference ignores joint ties)."""
+    x = np.array([1, 1, 2, 2, 3, 3, 4, 4], np.float32)
+    y = np.array([1, 2, 2, 3, 3, 3, 5, 4], np.float32)
+    ens = np.tile(y[:, None, None, None], (1, 2, 2, 2)).astype(np.float32)
+    engine.set_grid(2, 2, 2, 8)
+    engine.upload_members(ens)
+    got = engine.compute(Measure.KENDALL, reference_values=x)
+    assert (got == np.float32(0.833333254)).all()
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+def test_rank_nan_and_inf(engine, oracle, measure, omeasure):
+    rng = np.random.default_rng(5)
+    ens = rng.standard_normal((40, 4, 8, 16)).astype(np.float32)
+    ens[3, 1, 2, 3] = np.nan           # NaN in the query ensemble -> quiet NaN (CorrelationCalculator.cpp:929-940)
+    ens[39, 1, 2, 4] = np.nan
+    ens[0, 1, 2, 5] = np.inf           # infinities are ordinary ordered values
+    ens[7, 1, 2, 5] = np.inf
+    ens[9, 1, 2, 6] = -np.inf
+    got = _check(engine, oracle, ens, (0, 0, 0), measure, omeasure, f"{measure.name} nan/inf")
+    g = got.reshape(4, 8, 16)
+    assert np.isnan(g[1, 2, 3]) and np.isnan(g[1, 2, 4]) and np.isfinite(g[1, 2, 5])
+
+
+@pytest.mark.parametrize("measure", [Measure.SPEARMAN, Measure.KENDALL])
+def test_rank_single_member_is_one(engine, measure):
+    ens = synth.box_ensemble(8, 8, 4, 1)
+    engine.set_grid(8, 8, 4, 1)
+    engine.upload_members(ens)
+    assert (engine.compute(measure, (1, 1, 1)) == 1.0).all()
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+def test_rank_64cubed_16_members(engine, oracle, measure, omeasure):
+    ens = synth.box_ensemble(64, 64, 64, 16)
+    _check(engine, oracle, ens, (8, 8, 32), measure, omeasure, f"{measure.name} 64^3x16")
