@@ -10,7 +10,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -45,6 +47,7 @@ struct crf_context {
     float* d_ref = nullptr;    // cs reference values
     float* d_prep = nullptr;   // crf::kPrepBytes
     float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
+    double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
     uint32_t* d_minmax = nullptr;
     bool minmax_valid = false;
     float min_v = 0.f, max_v = 0.f;
@@ -96,6 +99,43 @@ int install_member_table(crf_context* c) {
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     c->minmax_valid = false;
     return CRF_OK;
+}
+
+// Host-built fp64 tables that depend on the member count only.
+//   psi(n) at integers: the reference calls boost::math::digamma on positive integers only
+//     (MutualInformation.cpp:235,237,438,439,503,504) = -gamma + H_{n-1}; accumulated in long double.
+//   T[c] = p ln p, p = c/cs: the value computeMutualInformationBinned adds for a bin holding c of cs samples
+//     (MutualInformation.cpp:120-140), evaluated with the host libm log like the reference.
+//   noise: the 1e-10 tie-breaking jitter of the Kraskov estimator (MutualInformation.cpp:409-420).  sgl's
+//     XorshiftRandomGenerator is not available (un-vendored, unpinned); this is the repo's documented stream:
+//     Marsaglia xorshift32 (13,17,5), seeds 617406168 / 864730169, u = (state >> 8) * 2^-24.
+std::vector<double> build_tables(int cs) {
+    std::vector<double> t(size_t(4 * cs + 2));
+    const long double gamma = 0.577215664901532860606512090082402431L;
+    long double h = 0.0L;
+    t[0] = std::numeric_limits<double>::quiet_NaN();
+    for (int n = 1; n <= cs; n++) {
+        t[size_t(n)] = double(h - gamma);
+        h += 1.0L / (long double)n;
+    }
+    double* T = t.data() + (cs + 1);
+    T[0] = 0.0;
+    for (int c = 1; c <= cs; c++) {
+        const double p = double(c) / double(cs);
+        T[c] = p * std::log(p);
+    }
+    const uint32_t seeds[2] = {617406168u, 864730169u};
+    for (int w = 0; w < 2; w++) {
+        uint32_t s = seeds[w];
+        double* dst = t.data() + 2 * (cs + 1) + w * cs;
+        for (int e = 0; e < cs; e++) {
+            s ^= s << 13;
+            s ^= s >> 17;
+            s ^= s << 5;
+            dst[e] = double(float(s >> 8) * (1.0f / 16777216.0f)) * 1e-10;
+        }
+    }
+    return t;
 }
 
 int check_ready(crf_context* c) {
@@ -174,6 +214,7 @@ void crf_destroy(crf_context* c) {
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_prep) (void)hipFree(c->d_prep);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     for (auto& p : c->ev_pending) {
         (void)hipEventDestroy(p.first);
@@ -196,6 +237,8 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (c->d_member_table) (void)hipFree(c->d_member_table);
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    c->d_tables = nullptr;
     c->d_member_table = nullptr;
     c->d_ref = nullptr;
     c->d_out = nullptr;
@@ -206,6 +249,9 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     c->num_voxels = n;
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_member_table), sizeof(float*) * size_t(cs)));
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ref), sizeof(float) * size_t(cs)));
+    const std::vector<double> tables = build_tables(cs);
+    CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_tables), tables.size() * sizeof(double)));
+    CRF_HIP(c, hipMemcpy(c->d_tables, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice));
     return CRF_OK;
 }
 
@@ -345,19 +391,20 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("binned MI supports at most %d members", crf::kMaxSortMembers));
             crf::BinnedArgs a{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
                               p->measure == CRF_BINNED_MI_CC};
-            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_prep, out, s, e0, e1,
-                                      &info);
+            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_tables, c->d_prep, out, s,
+                                      e0, e1, &info);
             break;
         }
         case CRF_MI_KRASKOV:
         case CRF_KMI_CC: {
-            if (p->k < 1) return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be >= 1", p->k));
+            if (p->k < 1 || (p->k > c->cs && c->cs > 1))
+                return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kraskov MI supports at most %d members", crf::kMaxSortMembers));
             const int est = p->kraskov_estimator_index == 2 ? 2 : 1;  // clamp as CorrelationCalculator.cpp:765
             crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC};
-            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_prep, out, s, e0, e1,
-                                       &info);
+            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_tables, c->d_prep, out, s,
+                                       e0, e1, &info);
             break;
         }
     }

@@ -49,16 +49,21 @@ struct BinnedArgs {
     float min_ref, max_ref, min_query, max_query;
     bool to_cc;
 };
+// d_tables (fp64, built on the host per member count, see build_tables() in api.cpp):
+//   [0, cs]            psi(n) = -gamma + H_{n-1}  (psi(0) = NaN)
+//   [cs+1, 2cs+1]      T[c] = (c/cs) * ln(c/cs)   (T[0] = 0)
+//   [2cs+2, 3cs+2)     noise_ref[e]   = double(u_e) * 1e-10, xorshift32 stream seeded 617406168
+//   [3cs+2, 4cs+2)     noise_query[e] = double(u_e) * 1e-10, xorshift32 stream seeded 864730169
 hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
-                            const BinnedArgs& a, float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin,
-                            hipEvent_t ev_end, LaunchInfo* info);
+                            const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                            hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 struct KraskovArgs {
     int k;
     int estimator;  // 1 or 2
     bool to_cc;
 };
 hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
-                             const KraskovArgs& a, float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin,
-                             hipEvent_t ev_end, LaunchInfo* info);
+                             const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
 }  // namespace crf

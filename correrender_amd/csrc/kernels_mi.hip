@@ -1,8 +1,490 @@
-// kernels_mi.hip -- placeholder until the mutual-information estimators land.
+// kernels_mi.hip -- the two mutual-information estimators on gfx950.
+//
+// Binned MI (computeMutualInformationBinned<double>, MutualInformation.cpp:45-143; driver
+// CorrelationCalculator.cpp:820-846,1026-1085).  The reference fills an 80x80 fp64 histogram per voxel although at
+// most cs cells are occupied.  Here one lane owns one voxel and works on the <= cs occupied cells only: each sample
+// becomes a 16-bit cell code (b1 << 8 | b0), the codes are sorted by a register min/max network, and one scan over
+// the sorted codes yields the run lengths of equal cells (joint histogram) and of equal b1 (query marginal).  With
+// every sample valid, a cell/marginal probability is c/cs for an integer count c, so p*ln(p) comes from a cs+1 entry
+// fp64 table built on the host with the same libm log as the reference; the reference-vector marginal is voxel
+// independent and is summed once per evaluation.  MI = -sum_x - sum_y + sum_xy, accumulated in fp64, returned as
+// float.  fp64 sums are taken in sorted-cell order, which is not the reference's bin-index order: a difference of
+// a few 1e-16 relative before the final cast to float (tolerance 1e-5 relative per the north star; in practice the
+// float results are bit-identical except at rounding boundaries).  Voxels with skipped samples (normalised value
+// NaN, MutualInformation.cpp:64 -- needs infinities in the data or max == min) take a compact O(cs^2) path.
+//
+// Kraskov kNN MI (KSG-1 computeMutualInformationKraskov<double>, MutualInformation.cpp:399-444; KSG-2 :449-509;
+// averageDigamma :167-259).  fp64 throughout, as the reference.  One lane owns one voxel; the voxel's cs values are
+// parked in that lane's LDS column; for each point a brute-force Chebyshev k-select over all points keeps the k+1
+// smallest distances in registers (sorted insertion, min/max only), then the marginal counts are brute-force
+// compares against [c-r, c+r); psi(n) comes from a table.  The tie-breaking noise (1e-10 * u) uses this repo's
+// documented xorshift32 stream, identical to oracle/corr_oracle.cpp (sgl's generator is not available).
+#include <cstdlib>
+
+#include "crf_device.h"
 #include "crf_internal.h"
+
 namespace crf {
-hipError_t launch_mi_binned(const float* const*, int, size_t, const float*, const BinnedArgs&, float*, float*,
-                            hipStream_t, hipEvent_t, hipEvent_t, LaunchInfo*) { return hipErrorNotSupported; }
-hipError_t launch_mi_kraskov(const float* const*, int, size_t, const float*, const KraskovArgs&, float*, float*,
-                             hipStream_t, hipEvent_t, hipEvent_t, LaunchInfo*) { return hipErrorNotSupported; }
+
+constexpr uint32_t kPadCode = 0xFFFFFFFFu;
+constexpr int kInvalidBin = 0xFFFF;
+
+// expf as the reference's host libm computes it.  The MI-correlation-coefficient map sqrt(1 - exp(-2 MI)) cancels
+// catastrophically for small MI (1 - exp(-2e-4) keeps ~11 bits), so a 1-ulp difference between two expf
+// implementations shows up as a 1e-4 relative difference in the result -- outside the 1e-5 tolerance.  glibc >= 2.27
+// evaluates expf in double precision with a 32-entry table of 2^(i/32) and a cubic (the ARM optimized-routines
+// algorithm: z = x*32/ln2, k = round(z), r = z-k, 2^(k/32) * (C0 r^3 + C1 r^2 + C2 r + 1)); the same IEEE fp64
+// operations in the same order give the same float (checked on the host against libm expf on 5e7 inputs).  The table
+// is 2^(i/32) rounded to double with i << 47 subtracted from its bits.
+__device__ const uint64_t kExp2Tab32[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float expf_host_libm(float x) {
+    if (!(x > -80.0f && x < 80.0f)) return expf(x);  // NaN, overflow/underflow range: never reached by -2*MI
+    const double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
+    const double shift = 0x1.8p+52;
+    const double c0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    const double c1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    const double c2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    double z = inv_ln2_n * double(x);
+    double kd = z + shift;
+    const uint64_t ki = uint64_t(__double_as_longlong(kd));
+    kd -= shift;
+    const double r = z - kd;
+    const uint64_t t = kExp2Tab32[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    z = c0 * r + c1;
+    const double r2 = r * r;
+    double y = c2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    return float(y);
 }
+
+__device__ __forceinline__ float mi_to_cc(float mi) {  // CorrelationCalculator.cpp:1071-1073,1130-1132
+    return sqrtf(1.0f - expf_host_libm(-2.0f * mi));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Binned MI: reference-side preparation.
+//   prep (int32 view): [0, N) b0_e (kInvalidBin when the normalised reference value is NaN), [N] = 1 if every reference
+//   sample is valid; prep (fp64 view) at byte offset 4096: SX = sum over occupied reference bins of p ln p.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void binned_prep_kernel(const float* __restrict__ ref, int cs, int n_pad, int nb,
+                                                         float min_ref, float max_ref,
+                                                         const double* __restrict__ tableT, int* __restrict__ prep) {
+    __shared__ int b0s[kMaxSortMembers];
+    __shared__ int all_valid;
+    if (threadIdx.x == 0) all_valid = 1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_pad; e += 64) {
+        int b = kInvalidBin;
+        if (e < cs) {
+            const float r01 = (ref[e] - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
+            if (r01 == r01) {
+                int t = int(double(r01) * double(nb));
+                b = t < 0 ? 0 : (t > nb - 1 ? nb - 1 : t);
+            } else {
+                atomicAnd(&all_valid, 0);
+            }
+            b0s[e] = b;
+        }
+        prep[e] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sx = 0.0;
+        for (int b = 0; b < nb; b++) {
+            int c = 0;
+            for (int e = 0; e < cs; e++) c += (b0s[e] == b);
+            sx += tableT[c];  // tableT[0] == 0
+        }
+        prep[n_pad] = all_valid;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(prep) + 4096) = sx;
+    }
+}
+
+template <int N, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* const* __restrict__ members,
+                                                                  const int* __restrict__ prep,
+                                                                  const double* __restrict__ tableT,
+                                                                  float* __restrict__ out, size_t num_voxels, int cs,
+                                                                  int nb, float min_q, float max_q, int to_cc) {
+    __shared__ double T[N + 1];
+    __shared__ uint16_t codes[N * 64];
+    const int lane = threadIdx.x;
+    for (int i = lane; i <= N; i += 64) T[i] = i <= cs ? tableT[i] : 0.0;
+    __syncthreads();
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const size_t vl = v < num_voxels ? v : num_voxels - 1;
+    const bool ref_all_valid = prep[N] != 0;
+    const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + 4096);
+
+    uint32_t a[N];
+    bool is_nan = false;
+    int total = 0;
+    const float range_q = max_q - min_q;
+    const double nbd = double(nb);
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        if (EXACT || e < cs) {
+            const float y = members[e][vl];
+            is_nan |= (y != y);
+            const float q01 = (y - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
+            const int b0 = prep[e];
+            const bool valid = (q01 == q01) && b0 != kInvalidBin;
+            int b1 = int(double(q01) * nbd);
+            b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
+            a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
+            total += valid ? 1 : 0;
+        } else {
+            a[e] = kPadCode;
+        }
+    }
+    const bool slow = (total != cs) || !ref_all_valid;
+    const bool any_slow = __any(slow);
+    if (any_slow) {
+#pragma unroll
+        for (int e = 0; e < N; e++)
+            if (EXACT || e < cs) codes[e * 64 + lane] = uint16_t(a[e] & 0xFFFFu);  // pad -> 0xFFFF
+    }
+
+    SortNet32<N>::sort(a);
+    double mi_y = -sx, joint = 0.0;
+    uint32_t cell_len = 0, col_len = 0;
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        if (EXACT || p < cs) {
+            uint32_t next = kPadCode;
+            if (p + 1 < N && (EXACT || p + 1 < cs)) next = a[p + 1];
+            cell_len++;
+            col_len++;
+            const bool end_cell = next != a[p];
+            const bool end_col = (next >> 8) != (a[p] >> 8);
+            joint += T[end_cell ? cell_len : 0u];
+            mi_y -= T[end_col ? col_len : 0u];
+            cell_len = end_cell ? 0u : cell_len;
+            col_len = end_col ? 0u : col_len;
+        }
+    }
+    double mi = mi_y + joint;
+
+    if (any_slow && slow) {
+        // Samples were skipped: probabilities are c/total with total < cs.  Direct O(cs^2) evaluation over the
+        // lane's LDS column; first occurrence of each bin/cell contributes its term.
+        mi = 0.0;
+        if (total > 0) {
+            const double tot = double(total);
+            const double eps1 = 0.5 / double(cs);
+            const double eps2 = 0.5 / double(cs * cs);
+#pragma unroll 1
+            for (int i = 0; i < cs; i++) {
+                const uint32_t ci = codes[i * 64 + lane];
+                if (ci == 0xFFFFu) continue;
+                int cx = 0, cy = 0, cxy = 0;
+                bool fx = true, fy = true, fxy = true;
+#pragma unroll 1
+                for (int j = 0; j < cs; j++) {
+                    const uint32_t cj = codes[j * 64 + lane];
+                    if (cj == 0xFFFFu) continue;
+                    const bool ex = (cj & 0xFFu) == (ci & 0xFFu);
+                    const bool ey = (cj >> 8) == (ci >> 8);
+                    cx += ex;
+                    cy += ey;
+                    cxy += (ex && ey);
+                    if (j < i) {
+                        fx = fx && !ex;
+                        fy = fy && !ey;
+                        fxy = fxy && !(ex && ey);
+                    }
+                }
+                if (fx) {
+                    const double p = double(cx) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fy) {
+                    const double p = double(cy) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fxy) {
+                    const double p = double(cxy) / tot;
+                    if (p > eps2) mi += p * log(p);
+                }
+            }
+        }
+    }
+    float res = float(mi);
+    if (to_cc) res = mi_to_cc(res);
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (v < num_voxels) out[v] = res;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kraskov
+// ---------------------------------------------------------------------------------------------------------
+// prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e   (MutualInformation.cpp:417-420)
+__global__ __launch_bounds__(64) void kraskov_prep_kernel(const float* __restrict__ ref, int cs,
+                                                          const double* __restrict__ noise_ref,
+                                                          double* __restrict__ prep) {
+    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = double(ref[e]) + noise_ref[e];
+}
+
+constexpr double kCountSlack = 1e-15;  // default_epsilon<double>::value, MutualInformation.cpp:163
+constexpr int kTI = 4;                 // points whose k-select runs concurrently per lane
+
+// KP1 > 0: k+1 = KP1 kept distances in registers.  KP1 == 0: any k, selection by repeated minimum passes.
+template <int KP1>
+__global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __restrict__ members,
+                                                        const double* __restrict__ prep_px,
+                                                        const double* __restrict__ table_psi,
+                                                        const double* __restrict__ noise_query,
+                                                        float* __restrict__ out, size_t num_voxels, int cs, int k,
+                                                        int estimator, int to_cc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* s_px = reinterpret_cast<double*>(smem);
+    double* s_nq = s_px + cs;
+    double* s_psi = s_nq + cs;                                     // cs + 1 entries: psi(0..cs)
+    float* s_y = reinterpret_cast<float*>(s_psi + (cs + 1) + ((cs + 1) & 1));  // keep 16-byte alignment
+    const int lane = threadIdx.x;
+    for (int i = lane; i < cs; i += 64) {
+        s_px[i] = prep_px[i];
+        s_nq[i] = noise_query[i];
+    }
+    for (int i = lane; i <= cs; i += 64) s_psi[i] = table_psi[i];
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const size_t vl = v < num_voxels ? v : num_voxels - 1;
+    bool is_nan = false;
+#pragma unroll 8
+    for (int e = 0; e < cs; e++) {
+        const float y = members[e][vl];
+        is_nan |= (y != y);
+        s_y[e * 64 + lane] = y;
+    }
+    __syncthreads();
+
+    const int kk = k < cs - 1 ? k : cs - 1;  // (kk+1)-th smallest distance including the point itself
+    const double factor = 1.0 / double(cs);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double sum_x = 0.0, sum_y = 0.0;
+
+#pragma unroll 1
+    for (int i0 = 0; i0 < cs; i0 += kTI) {
+        double pxi[kTI], pyi[kTI], rx[kTI], ry[kTI];
+#pragma unroll
+        for (int t = 0; t < kTI; t++) {
+            const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
+            pxi[t] = s_px[ii];
+            pyi[t] = double(s_y[ii * 64 + lane]) + s_nq[ii];
+        }
+        // ---- pass A: distance to the k-th neighbour (Chebyshev), MutualInformation.cpp:430-434
+        double dk[kTI];
+        if constexpr (KP1 > 0) {
+            double best[kTI][KP1];
+#pragma unroll
+            for (int t = 0; t < kTI; t++)
+#pragma unroll
+                for (int q = 0; q < KP1; q++) best[t][q] = inf;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const double pxj = s_px[j];
+                const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
+#pragma unroll
+                for (int t = 0; t < kTI; t++) {
+                    double d = fmax(fabs(pxi[t] - pxj), fabs(pyi[t] - pyj));
+#pragma unroll
+                    for (int q = 0; q < KP1; q++) {
+                        const double lo = fmin(best[t][q], d);
+                        d = fmax(best[t][q], d);
+                        best[t][q] = lo;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kTI; t++) dk[t] = best[t][KP1 - 1];
+        } else {
+#pragma unroll
+            for (int t = 0; t < kTI; t++) {
+                double cur = -1.0, m = 0.0;
+                int cnt = 0;
+#pragma unroll 1
+                for (int pass = 0; pass <= kk; pass++) {
+                    m = inf;
+                    int c = 0;
+#pragma unroll 2
+                    for (int j = 0; j < cs; j++) {
+                        const double pxj = s_px[j];
+                        const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
+                        const double d = fmax(fabs(pxi[t] - pxj), fabs(pyi[t] - pyj));
+                        if (d > cur) {
+                            c = (d < m) ? 1 : (d == m ? c + 1 : c);
+                            m = fmin(m, d);
+                        }
+                    }
+                    cnt += c;
+                    if (cnt >= kk + 1) break;
+                    cur = m;
+                }
+                dk[t] = m;
+            }
+        }
+        // ---- search radii
+        if (estimator == 1) {
+#pragma unroll
+            for (int t = 0; t < kTI; t++) rx[t] = ry[t] = dk[t] - kCountSlack;  // includeCenter, :196-197
+        } else {
+            // KSG-2: extents of the k+1 nearest points per dimension (:485-499), then +slack (:198-199)
+            double ex[kTI], ey[kTI];
+#pragma unroll
+            for (int t = 0; t < kTI; t++) ex[t] = ey[t] = 0.0;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const double pxj = s_px[j];
+                const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
+#pragma unroll
+                for (int t = 0; t < kTI; t++) {
+                    const double ax = fabs(pxi[t] - pxj), ay = fabs(pyi[t] - pyj);
+                    const bool in = fmax(ax, ay) <= dk[t];
+                    ex[t] = in ? fmax(ex[t], ax) : ex[t];
+                    ey[t] = in ? fmax(ey[t], ay) : ey[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kTI; t++) {
+                rx[t] = ex[t] + kCountSlack;
+                ry[t] = ey[t] + kCountSlack;
+            }
+        }
+        // ---- pass C: marginal counts  #{ j : c - r <= v_j < c + r }  (:201-233)
+        double lox[kTI], hix[kTI], loy[kTI], hiy[kTI];
+        int cx[kTI], cy[kTI];
+#pragma unroll
+        for (int t = 0; t < kTI; t++) {
+            lox[t] = pxi[t] - rx[t];
+            hix[t] = pxi[t] + rx[t];
+            loy[t] = pyi[t] - ry[t];
+            hiy[t] = pyi[t] + ry[t];
+            cx[t] = cy[t] = 0;
+        }
+#pragma unroll 2
+        for (int j = 0; j < cs; j++) {
+            const double pxj = s_px[j];
+            const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
+#pragma unroll
+            for (int t = 0; t < kTI; t++) {
+                cx[t] += (pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
+                cy[t] += (pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kTI; t++) {
+            if (i0 + t < cs) {
+                int nx = cx[t] > 1 ? cx[t] : 1;
+                int ny = cy[t] > 1 ? cy[t] : 1;
+                if (estimator != 1) {
+                    nx -= 1;  // psi(n - 1), psi(0) = NaN (pole)
+                    ny -= 1;
+                }
+                sum_x += factor * s_psi[nx];
+                sum_y += factor * s_psi[ny];
+            }
+        }
+    }
+    double c = s_psi[k <= cs ? k : cs];
+    if (estimator != 1) c -= 1.0 / double(k);
+    const double d = s_psi[cs];
+    const double mi = -sum_x - sum_y + c + d;
+    float res = float(mi);
+    res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
+    if (to_cc) res = mi_to_cc(res);
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (v < num_voxels) out[v] = res;
+}
+
+namespace {
+
+template <int N, int MIN_WAVES>
+void launch_binned_n(const float* const* d_members, const int* prep, const double* tableT, float* d_out,
+                     size_t num_voxels, int cs, const BinnedArgs& a, hipStream_t s) {
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    if (cs == N)
+        hipLaunchKernelGGL((mi_binned_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, prep,
+                           tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
+    else
+        hipLaunchKernelGGL((mi_binned_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, prep,
+                           tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
+}
+
+int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
+
+}  // namespace
+
+hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                            const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                            hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    if (cs == 1) {
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        if (info) info->kernel_name = "fill_kernel";
+        return e;
+    }
+    const int n_pad = pad_pow2(cs);
+    int* prep = reinterpret_cast<int*>(d_prep);
+    const double* tableT = d_tables + (cs + 1);
+    hipLaunchKernelGGL(binned_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, n_pad, a.num_bins, a.min_ref, a.max_ref,
+                       tableT, prep);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    switch (n_pad) {
+        case 16: launch_binned_n<16, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 32: launch_binned_n<32, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 64: launch_binned_n<64, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        default: launch_binned_n<128, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+    }
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "mi_binned_kernel";
+    return hipGetLastError();
+}
+
+hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+                             const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    if (cs == 1) {
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        if (info) info->kernel_name = "fill_kernel";
+        return e;
+    }
+    const double* psi = d_tables;
+    const double* noise_ref = d_tables + 2 * (cs + 1);
+    const double* noise_query = noise_ref + cs;
+    double* prep = reinterpret_cast<double*>(d_prep);
+    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, noise_ref, prep);
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    const size_t lds = size_t(3 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
+    const int kk = a.k < cs - 1 ? a.k : cs - 1;
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+#define CRF_LAUNCH_KRASKOV(KP1)                                                                                      \
+    hipLaunchKernelGGL((mi_kraskov_kernel<KP1>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
+                       d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
+    switch (kk + 1) {
+        case 2: CRF_LAUNCH_KRASKOV(2); break;
+        case 3: CRF_LAUNCH_KRASKOV(3); break;
+        case 4: CRF_LAUNCH_KRASKOV(4); break;
+        case 5: CRF_LAUNCH_KRASKOV(5); break;
+        default: CRF_LAUNCH_KRASKOV(0); break;
+    }
+#undef CRF_LAUNCH_KRASKOV
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "mi_kraskov_kernel";
+    return hipGetLastError();
+}
+
+}  // namespace crf
