@@ -227,9 +227,10 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     if (cs <= kMaxRegisterMembers) {
         const int cs_pad = cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 48 ? 48 : cs <= 64 ? 64 : cs <= 96 ? 96
                          : cs <= 128 ? 128 : cs <= 192 ? 192 : 256;
-        // voxels per lane: default keeps cs_pad*vpt <= 128 data VGPRs (>= 2-3 waves/SIMD); CRF_PEARSON_VPT overrides
-        // for tuning experiments.
-        int vpt = cs_pad <= 32 ? 4 : (cs_pad <= 64 ? 2 : 1);
+        // voxels per lane.  Measured on MI355X at 256^3 x 64 (profiles/): one voxel per lane (dword loads, 93 VGPRs,
+        // 5 waves/SIMD) reaches 5.7 TB/s; 2 per lane (196 VGPRs, 2 waves/SIMD) 4.9 TB/s; 4 per lane 3.4 TB/s --
+        // occupancy, not load width, is what keeps HBM busy here.  CRF_PEARSON_VPT overrides for tuning experiments.
+        int vpt = cs_pad <= 16 ? 2 : 1;
         vpt = env_int("CRF_PEARSON_VPT", vpt);
         if (vpt > max_vpt) vpt = max_vpt;
         while (vpt > 1 && cs_pad * vpt > 256) vpt >>= 1;

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz -- small input/output vectors for the correlation-field path.
+
+Run in the BUILD container only (needs oracle/_ref/libref_corr.so, i.e. /root/reference):  python oracle/make_golden.py
+  * Pearson / Spearman / Kendall expected outputs come from the REFERENCE's own object code
+    (src/Calculators/Correlation.cpp compiled where it lies, driven by oracle/ref_driver.cpp).
+  * binned / Kraskov MI expected outputs come from this repo's CPU restatement (oracle/corr_oracle.cpp): the
+    reference's MutualInformation.cpp cannot be built here (boost, sgl, glm absent) -- those files are labelled
+    "restatement" and pin the restatement against regressions, not against the reference ("parity unpinned").
+Inputs are regenerated from seeds by this script; the arrays are stored so that the fixtures are self-contained data.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib  # noqa: E402
+from correrender_amd import synth  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+
+
+def case_inputs():
+    """name -> (members [cs, zs, ys, xs] float32, reference values [cs] float32)"""
+    cases = {}
+    for cs in (16, 64):
+        ens = synth.box_ensemble(16, 16, 8, cs, seed=20260130 + cs)
+        cases[f"box_16x16x8_cs{cs}_center"] = (ens, ens[:, 4, 8, 8].copy())
+        cases[f"box_16x16x8_cs{cs}_inbox"] = (ens, ens[:, 4, 2, 2].copy())
+    rng = np.random.default_rng(7)
+    ties = np.round(rng.standard_normal((24, 4, 8, 8)) * 1.5).astype(np.float32)       # tie-heavy
+    ties[:, 0, 0, 0] = 1.0
+    ties[:, 0, 0, 1] = np.arange(24)
+    cases["ties_8x8x4_cs24"] = (ties, ties[:, 2, 3, 4].copy())
+    nan = rng.standard_normal((12, 2, 4, 8)).astype(np.float32)                      # a NaN-containing voxel
+    nan[5, 1, 2, 3] = np.nan
+    cases["nan_8x4x2_cs12"] = (nan, nan[:, 0, 0, 0].copy())
+    one = synth.box_ensemble(8, 8, 4, 1, seed=3)                                       # cs == 1
+    cases["single_member_8x8x4"] = (one, one[:, 2, 4, 4].copy())
+    iid = synth.normal_ensemble(16, 8, 4, 64, seed=99)                                 # tie-free (Kraskov)
+    cases["normal_16x8x4_cs64"] = (iid, iid[:, 2, 4, 8].copy())
+    return cases
+
+
+def main():
+    if not oracle_lib.reference_available():
+        raise SystemExit("oracle/_ref/libref_corr.so missing: run `make -C oracle` where /root/reference exists")
+    ref = oracle_lib.load_reference()
+    oracle = oracle_lib.load_oracle()
+    OUT.mkdir(parents=True, exist_ok=True)
+    for name, (ens, refv) in case_inputs().items():
+        cs = ens.shape[0]
+        mn, mx = oracle.minmax(ens) if np.isfinite(ens).all() else (float(np.nanmin(ens)), float(np.nanmax(ens)))
+        k = max(-(-3 * cs // 100), 1)
+        data = dict(members=ens, reference_values=refv, minmax=np.array([mn, mx], np.float32), k=np.int32(k),
+                    num_bins=np.int32(80))
+        data["pearson__reference"] = ref.field(0, ens, refv)
+        data["spearman__reference"] = ref.field(1, ens, refv)
+        data["kendall__reference"] = ref.field(2, ens, refv)
+        data["mi_binned__restatement"] = oracle.field(oracle_lib.MI_BINNED, ens, refv, num_bins=80, minmax_ref=(mn, mx))
+        data["binned_mi_cc__restatement"] = oracle.field(oracle_lib.BINNED_MI_CC, ens, refv, num_bins=80,
+                                                         minmax_ref=(mn, mx))
+        data["mi_kraskov__restatement"] = oracle.field(oracle_lib.MI_KRASKOV, ens, refv, k=k)
+        data["mi_kraskov_k3__restatement"] = oracle.field(oracle_lib.MI_KRASKOV, ens, refv, k=min(3, max(cs - 1, 1)))
+        data["mi_kraskov2__restatement"] = oracle.field(oracle_lib.MI_KRASKOV, ens, refv, k=k, estimator=2)
+        data["kmi_cc__restatement"] = oracle.field(oracle_lib.KMI_CC, ens, refv, k=k)
+        np.savez_compressed(OUT / f"{name}.npz", **data)
+        print(f"{name}: cs={cs} voxels={ens[0].size} -> {(OUT / (name + '.npz')).stat().st_size} bytes")
+    # known-answer vectors (computed by the reference object code)
+    x = np.array([1, 1, 2, 2, 3, 3, 4, 4], np.float32)
+    y = np.array([1, 2, 2, 3, 3, 3, 5, 4], np.float32)
+    ka = dict(x=x, y=y, kendall__reference=np.float32(ref.kendall(x, y)),
+              kendall_slow__reference=np.float32(ref.kendall_slow(x, y)),
+              pearson__reference=np.float32(ref.pearson(x, y)), ranks_y__reference=ref.ranks(y))
+    np.savez_compressed(OUT / "known_answers.npz", **ka)
+    print("known_answers:", {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in ka.items() if "__" in k})
+
+
+if __name__ == "__main__":
+    main()
