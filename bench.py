@@ -68,55 +68,45 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # one rank per GPU; CRF_BENCH_BACKEND=gloo lets several ranks share one GPU for rehearsals on a 1-GPU box
+    backend = os.environ.get("CRF_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     xs, ys, zs = args.grid
     cs = args.members
     measure = ca.Measure(ca.MEASURE_IDS.index(args.measure))
-    if zs % world != 0:
-        raise SystemExit(f"zs={zs} must be divisible by the number of GPUs ({world})")
-    zl = zs // world
-    z0 = rank * zl
+    from correrender_amd.distributed import ShardedCorrField
+    eng = ca.CorrField(local_rank)
+    sharded = ShardedCorrField(eng, (xs, ys, zs), cs, rank=rank, world=world, device=torch.device("cuda", local_rank))
+    z0, zl = sharded.z_begin, sharded.z_count
     n_local = xs * ys * zl
     n_total = xs * ys * zs
-
-    eng = ca.CorrField(local_rank)
-    eng.set_grid(xs, ys, zl, cs)
     members = torch.empty((cs, zl, ys, xs), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     for c in range(cs):
         eng.synth_box_member(members[c], xs, ys, zl, z0, zs, c, cs, args.seed, stream)
     torch.cuda.synchronize()
-    eng.bind_members(members)
+    sharded.bind_members(members)
     out = torch.empty(n_local, dtype=torch.float32, device="cuda")
-    ref_bufs = [torch.empty(cs, dtype=torch.float32, device="cuda") for _ in range(2)]
     kwargs = {}
     if measure in (ca.Measure.MUTUAL_INFORMATION_BINNED, ca.Measure.BINNED_MI_CORRELATION_COEFFICIENT):
-        mn, mx = eng.member_minmax()
-        if world > 1:
-            t = torch.tensor([mn, -mx], device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            mn, mx = float(t[0]), float(-t[1])
-        kwargs = dict(minmax_ref=(mn, mx), minmax_query=(mn, mx))
+        mm = sharded.global_minmax()
+        kwargs = dict(minmax_ref=mm, minmax_query=mm)
     if measure in (ca.Measure.MUTUAL_INFORMATION_KRASKOV, ca.Measure.KMI_CORRELATION_COEFFICIENT):
         kwargs = dict(k=3)  # BASELINE.json configs[2]
 
     pts = reference_points(xs, ys, zs, args.warmup + args.steps)
 
     def step(i):
-        x, y, z = pts[i]
-        if world == 1:
-            eng.compute_device(measure, out, (x, y, z), stream=stream, **kwargs)
-        else:
-            owner = z // zl
-            buf = ref_bufs[i & 1]
-            if rank == owner:
-                eng.gather_reference_device(x, y, z - z0, buf, stream)
-            dist.broadcast(buf, src=owner)
-            eng.compute_device(measure, out, device_reference=buf, stream=stream, **kwargs)
+        # owner rank gathers the reference vector on its device -> broadcast (RCCL) -> every rank evaluates its slab
+        sharded.compute(measure, out, pts[i], stream=stream, **kwargs)
 
     def fence():
         torch.cuda.synchronize()

@@ -59,17 +59,24 @@ struct VecT<1> {
 };
 template <>
 struct VecT<2> {
-    using type = float2;
+    using type = float __attribute__((ext_vector_type(2)));
 };
 template <>
 struct VecT<4> {
-    using type = float4;
+    using type = float __attribute__((ext_vector_type(4)));
 };
 
-template <int VPT>
+// Member values are read exactly once per evaluation and the ensemble (4.3 GB at 256^3 x 64) is far larger than the
+// 256 MiB Infinity Cache, so the loads are issued non-temporal (`nt`): measured 0.753 -> 0.705 ms at 256^3 x 64
+// (5.79 -> 6.19 TB/s) on MI355X, profiles/tuning_r01.md.
+template <int VPT, bool NT>
 __device__ __forceinline__ void load_vec(const float* p, float (&dst)[VPT]) {
     using V = typename VecT<VPT>::type;
-    const V v = *reinterpret_cast<const V*>(p);
+    V v;
+    if constexpr (NT)
+        v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    else
+        v = *reinterpret_cast<const V*>(p);
     __builtin_memcpy(dst, &v, sizeof(V));
 }
 template <int VPT>
@@ -80,16 +87,16 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
     *reinterpret_cast<V*>(p) = v;
 }
 
-template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES>
-__global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
-                                                                     const float* __restrict__ prep,
-                                                                     float* __restrict__ out, size_t voxel_offset,
-                                                                     int cs) {
-    const size_t v0 = voxel_offset + (size_t(blockIdx.x) * 256 + threadIdx.x) * VPT;
+template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES, int BLOCK = 256, bool NT = true>
+__global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
+                                                                       const float* __restrict__ prep,
+                                                                       float* __restrict__ out, size_t voxel_offset,
+                                                                       int cs) {
+    const size_t v0 = voxel_offset + (size_t(blockIdx.x) * BLOCK + threadIdx.x) * VPT;
     float y[CS_PAD][VPT];
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) load_vec<VPT>(members[e] + v0, y[e]);
+        if (EXACT || e < cs) load_vec<VPT, NT>(members[e] + v0, y[e]);
     }
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -235,6 +242,26 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
         if (vpt > max_vpt) vpt = max_vpt;
         while (vpt > 1 && cs_pad * vpt > 256) vpt >>= 1;
         if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 1;
+        const int variant = env_int("CRF_PEARSON_VARIANT", 0);
+        if (variant > 0 && cs == 64) {  // tuning experiments (tools/tune_pearson.py), one voxel per lane
+#define CRF_VARIANT(MINW, BLK, NT_)                                                                              \
+    {                                                                                                            \
+        const size_t blocks_ = num_voxels / BLK;                                                                 \
+        covered = blocks_ * BLK;                                                                                 \
+        if (blocks_ > 0)                                                                                         \
+            hipLaunchKernelGGL((pearson_reg_kernel<64, 1, true, MINW, BLK, NT_>), dim3(unsigned(blocks_)),       \
+                               dim3(BLK), 0, s, d_members, d_prep, d_out, size_t(0), cs);                        \
+    }
+            switch (variant) {
+                case 1: CRF_VARIANT(4, 256, false); break;  // temporal (default-policy) loads
+                case 2: CRF_VARIANT(2, 512, true); break;   // 512-thread blocks
+                case 3: CRF_VARIANT(6, 256, true); break;   // register cap for 6 waves/SIMD
+                default: CRF_VARIANT(4, 256, true); break;
+            }
+#undef CRF_VARIANT
+            if (info) info->kernel_name = "pearson_reg_kernel";
+            goto tail;
+        }
         const size_t per_block = size_t(256) * vpt;
         const size_t blocks = num_voxels / per_block;
         covered = blocks * per_block;
@@ -254,6 +281,7 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     } else {
         if (info) info->kernel_name = "pearson_stream_kernel";
     }
+tail:
     if (covered < num_voxels) {
         const size_t rest = num_voxels - covered;
         hipLaunchKernelGGL(pearson_stream_kernel, dim3(unsigned((rest + 255) / 256)), dim3(256), 0, s, d_members,

@@ -1,0 +1,110 @@
+"""Multi-GPU correlation field: z-slab sharding, one process per GPU, torch.distributed (RCCL over xGMI on ROCm).
+
+The reference has no distributed path (zero collective call sites); this is new, MI355X-native
+work.  Voxels are independent given the cs-float reference vector, so the grid shards by z-slab -- with x-fastest
+volumes (IDXS, src/Loaders/DataSet.hpp:37) a slab of every member is one contiguous range and output slabs concatenate
+-- and ONE exchange step remains per evaluation: the rank that owns the reference point's slice gathers
+referenceValues[c] = member_c[IDXS(ref)] (CorrelationCalculator.cpp:802,815-817) on its device and broadcasts those
+cs floats (<= 1 KiB, latency-bound).  The binned-MI measures additionally need the global extrema of the members
+(CorrelationCalculator.cpp:822-829): an all-reduce of two floats, once per data set.
+
+Everything is stream-ordered on the caller's stream: no host synchronisation inside `compute`.
+The compute backend is any object with the CorrField device interface (set_grid / gather_reference_device /
+compute_device / member_minmax); the product backend is correrender_amd.CorrField (HIP kernels).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+from .engine import Measure
+
+
+def slab_bounds(zs: int, world: int, rank: int) -> Tuple[int, int]:
+    """(z_begin, z_count) of `rank`'s slab: ceil-split, the first zs % world ranks get one extra slice."""
+    base, rem = divmod(zs, world)
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
+def slab_owner(zs: int, world: int, z: int) -> Tuple[int, int]:
+    """(owner rank, local z) of global slice z."""
+    if not 0 <= z < zs:
+        raise ValueError(f"z={z} outside [0,{zs})")
+    base, rem = divmod(zs, world)
+    split = rem * (base + 1)
+    if z < split:
+        r = z // (base + 1)
+    else:
+        r = rem + (z - split) // base
+    z0, _ = slab_bounds(zs, world, r)
+    return r, z - z0
+
+
+_BINNED = (Measure.MUTUAL_INFORMATION_BINNED, Measure.BINNED_MI_CORRELATION_COEFFICIENT)
+
+
+class ShardedCorrField:
+    """One rank's share of a z-slab-sharded correlation field evaluation."""
+
+    def __init__(self, engine, grid: Tuple[int, int, int], cs: int, *, rank: Optional[int] = None,
+                 world: Optional[int] = None, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.engine = engine
+        self.group = group
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if world > 1 else 0
+        self.rank, self.world = rank, world
+        self.xs, self.ys, self.zs = grid
+        self.cs = cs
+        self.z_begin, self.z_count = slab_bounds(self.zs, world, rank)
+        if self.z_count <= 0:
+            raise ValueError(f"rank {rank} of {world} owns no slice of a grid with zs={self.zs}")
+        self.device = device if device is not None else torch.device("cpu")
+        engine.set_grid(self.xs, self.ys, self.z_count, cs)
+        # two reference-vector buffers, alternated, so that a broadcast for step i+1 never overwrites the vector a
+        # still-running kernel of step i reads
+        self._ref = [torch.empty(cs, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._flip = 0
+        self._minmax = None
+
+    @property
+    def local_voxels(self) -> int:
+        return self.xs * self.ys * self.z_count
+
+    def _global_rank(self, r: int) -> int:
+        return self._dist.get_global_rank(self.group, r) if (self.group is not None and self.world > 1) else r
+
+    def bind_members(self, members):
+        """members: this rank's slab of every member ([cs, z_count, ys, xs] or a list of cs tensors)."""
+        self.engine.bind_members(members)
+        self._minmax = None
+
+    def global_minmax(self) -> Tuple[float, float]:
+        """min of mins / max of maxes over all members and all slabs (binned MI normalisation range)."""
+        if self._minmax is None:
+            mn, mx = self.engine.member_minmax()
+            if self.world > 1:
+                t = self._torch.tensor([mn, -mx], dtype=self._torch.float32, device=self.device)
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+                mn, mx = float(t[0]), float(-t[1])
+            self._minmax = (mn, mx)
+        return self._minmax
+
+    def compute(self, measure, out, ref_xyz, *, stream: int = 0, **kw):
+        """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats)."""
+        x, y, z = ref_xyz
+        owner, local_z = slab_owner(self.zs, self.world, z)
+        if int(measure) in _BINNED and "minmax_ref" not in kw:
+            mm = self.global_minmax()
+            kw = dict(kw, minmax_ref=mm, minmax_query=mm)
+        buf = self._ref[self._flip]
+        self._flip ^= 1
+        if self.rank == owner:
+            self.engine.gather_reference_device(x, y, local_z, buf, stream)
+        if self.world > 1:
+            self._dist.broadcast(buf, src=self._global_rank(owner), group=self.group)
+        self.engine.compute_device(measure, out, device_reference=buf, stream=stream, **kw)
+        return out

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Summarises a profiles/collect.sh output directory: per-kernel duration statistics from the rocprofv3 kernel trace
+and HBM traffic per launch from the PMC passes, with the gfx950 unit handling of MI355X_MICROARCH.md section HBM:
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-byte requests at 64 bytes for wide coalesced
+streaming reads (x2 correction), calibrated in this same profile on kernels whose byte counts are known exactly
+(minmax_kernel reads cs*M*4 bytes with 16-B/lane loads; synth_box_kernel writes M*4 bytes per launch)."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+from collections import defaultdict
+
+
+def rows(pattern):
+    for f in glob.glob(pattern, recursive=True):
+        with open(f, newline="") as fh:
+            yield from csv.DictReader(fh)
+
+
+def short(name):
+    name = name.split("(")[0]
+    for key in ("pearson_reg_kernel", "pearson_stream_kernel", "pearson_prep_kernel", "spearman_kernel", "kendall_kernel",
+                "mi_binned_kernel", "mi_kraskov_kernel", "minmax_kernel", "synth_box_kernel", "gather_reference_kernel",
+                "fill_kernel"):
+        if key in name:
+            return key
+    return name[-60:]
+
+
+def main():
+    out = sys.argv[1]
+    dur = defaultdict(list)
+    for r in rows(os.path.join(out, "trace", "**", "*kernel_trace.csv")):
+        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(f"# rocprofv3 summary ({' '.join(sys.argv[2:])})\n")
+    print("| kernel | launches | avg us | median us | min us | total ms |")
+    print("|---|---|---|---|---|---|")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print(f"| {k} | {len(v)} | {statistics.mean(v):.1f} | {statistics.median(v):.1f} | {min(v):.1f} | {sum(v) / 1e3:.2f} |")
+    pmc = {}
+    for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        acc = defaultdict(list)
+        for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
+            if r.get("Counter_Name") == name:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        pmc[name] = {k: statistics.mean(v) for k, v in acc.items()}
+    print("\n| kernel | FETCH_SIZE KiB/launch (raw) | x2-corrected GB | WRITE_SIZE KiB/launch | GB |")
+    print("|---|---|---|---|---|")
+    for k in sorted(set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"])):
+        f = pmc["FETCH_SIZE"].get(k, float("nan"))
+        w = pmc["WRITE_SIZE"].get(k, float("nan"))
+        print(f"| {k} | {f:.0f} | {f * 1024 * 2 / 1e9:.4f} | {w:.0f} | {w * 1024 / 1e9:.4f} |")
+    with open(os.path.join(out, "summary.json"), "w") as fh:
+        json.dump({"durations_us": {k: {"n": len(v), "avg": statistics.mean(v), "median": statistics.median(v)}
+                                    for k, v in dur.items()}, "pmc_kib_per_launch": pmc}, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
