@@ -345,18 +345,17 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     float* out = static_cast<float*>(device_out);
 
-    // 1. reference vector -> device (CorrelationCalculator.cpp:802-818)
-    const float* d_ref = static_cast<const float*>(device_reference_values);
-    if (!d_ref) {
+    // 1. reference vector (CorrelationCalculator.cpp:802-818): a device array, a host array (copied stream-ordered),
+    //    or the reference point -- then the gather is fused into the estimator's preparation kernel.
+    crf::RefSource ref{static_cast<const float*>(device_reference_values), 0};
+    if (!ref.values) {
         if (p->reference_values) {
             CRF_HIP(c, hipMemcpyAsync(c->d_ref, p->reference_values, sizeof(float) * size_t(c->cs),
                                       hipMemcpyHostToDevice, s));
+            ref.values = c->d_ref;
         } else {
-            size_t voxel;
-            if (int r = ref_voxel(c, p->ref_x, p->ref_y, p->ref_z, &voxel)) return r;
-            CRF_HIP(c, crf::launch_gather_reference(c->d_member_table, c->cs, voxel, c->d_ref, s));
+            if (int r = ref_voxel(c, p->ref_x, p->ref_y, p->ref_z, &ref.voxel)) return r;
         }
-        d_ref = c->d_ref;
     }
 
     // 2. estimator
@@ -370,18 +369,18 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     hipError_t e = hipSuccess;
     switch (p->measure) {
         case CRF_PEARSON:
-            e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, d_ref, c->d_prep, out, s, e0, e1,
+            e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, ref, c->d_prep, out, s, e0, e1,
                                     &info);
             break;
         case CRF_SPEARMAN:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
-            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, d_ref, c->d_prep, out, s, e0, e1, &info);
+            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, out, s, e0, e1, &info);
             break;
         case CRF_KENDALL:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
-            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, d_ref, c->d_prep, out, s, e0, e1, &info);
+            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, out, s, e0, e1, &info);
             break;
         case CRF_MI_BINNED:
         case CRF_BINNED_MI_CC: {
@@ -391,7 +390,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("binned MI supports at most %d members", crf::kMaxSortMembers));
             crf::BinnedArgs a{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
                               p->measure == CRF_BINNED_MI_CC};
-            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_tables, c->d_prep, out, s,
+            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, c->d_prep, out, s,
                                       e0, e1, &info);
             break;
         }
@@ -403,7 +402,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kraskov MI supports at most %d members", crf::kMaxSortMembers));
             const int est = p->kraskov_estimator_index == 2 ? 2 : 1;  // clamp as CorrelationCalculator.cpp:765
             crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC};
-            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, d_ref, a, c->d_tables, c->d_prep, out, s,
+            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, c->d_prep, out, s,
                                        e0, e1, &info);
             break;
         }

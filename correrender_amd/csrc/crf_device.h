@@ -3,7 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "crf_internal.h"
+
 namespace crf {
+
+__device__ __forceinline__ float load_ref(const RefSource& r, const float* const* __restrict__ members, int c) {
+    return r.values ? r.values[c] : members[c][r.voxel];
+}
 
 // Order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b) for non-NaN a, b; -0.0 must have been
 // canonicalised to +0.0 by the caller with `y + 0.0f` so that key equality == float equality).

@@ -15,6 +15,14 @@ constexpr int kMaxSortMembers = 128;
 // Prepared reference-derived table: floats (see each kernels_*.hip for its layout).
 constexpr size_t kPrepBytes = 64 * 1024;
 
+// Where a preparation kernel takes the reference vector from: an explicit device array of cs floats (SEPARATE mode,
+// or a vector received from another rank), or -- fused gather -- members[c][voxel]
+// (referenceValues[c] = fields[c][IDXS(ref)], CorrelationCalculator.cpp:802,815-817).
+struct RefSource {
+    const float* values;  // non-null: use values[c]
+    size_t voxel;         // else: members[c][voxel]
+};
+
 struct LaunchInfo {
     const char* kernel_name = "";  // dominant per-voxel kernel (for rocprof row matching)
 };
@@ -30,16 +38,16 @@ hipError_t launch_synth_box_member(float* d_out, int xs, int ys, int zs_local, i
 // ---- kernels_pearson.hip ----------------------------------------------------------------------------------
 // d_ref: cs reference values on the device.  d_prep: scratch of kPrepBytes.  Writes num_voxels floats to d_out.
 // max_vpt: widest per-lane vector (1, 2 or 4 floats) the member/output pointers are aligned for.
-hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const float* d_ref,
+hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const RefSource& ref,
                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           LaunchInfo* info);
 hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s);
 
 // ---- kernels_rank.hip (Spearman, Kendall) ---------------------------------------------------------------
-hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                            float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                            LaunchInfo* info);
-hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           LaunchInfo* info);
 
@@ -54,7 +62,7 @@ struct BinnedArgs {
 //   [cs+1, 2cs+1]      T[c] = (c/cs) * ln(c/cs)   (T[0] = 0)
 //   [2cs+2, 3cs+2)     noise_ref[e]   = double(u_e) * 1e-10, xorshift32 stream seeded 617406168
 //   [3cs+2, 4cs+2)     noise_query[e] = double(u_e) * 1e-10, xorshift32 stream seeded 864730169
-hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                             const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 struct KraskovArgs {
@@ -62,7 +70,7 @@ struct KraskovArgs {
     int estimator;  // 1 or 2
     bool to_cc;
 };
-hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 

@@ -77,8 +77,8 @@ __device__ __forceinline__ float mi_to_cc(float mi) {  // CorrelationCalculator.
 //   prep (int32 view): [0, N) b0_e (kInvalidBin when the normalised reference value is NaN), [N] = 1 if every reference
 //   sample is valid; prep (fp64 view) at byte offset 4096: SX = sum over occupied reference bins of p ln p.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void binned_prep_kernel(const float* __restrict__ ref, int cs, int n_pad, int nb,
-                                                         float min_ref, float max_ref,
+__global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                         int cs, int n_pad, int nb, float min_ref, float max_ref,
                                                          const double* __restrict__ tableT, int* __restrict__ prep) {
     __shared__ int b0s[kMaxSortMembers];
     __shared__ int all_valid;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void binned_prep_kernel(const float* __restrict
     for (int e = threadIdx.x; e < n_pad; e += 64) {
         int b = kInvalidBin;
         if (e < cs) {
-            const float r01 = (ref[e] - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
+            const float r01 = (load_ref(src, members, e) - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
             if (r01 == r01) {
                 int t = int(double(r01) * double(nb));
                 b = t < 0 ? 0 : (t > nb - 1 ? nb - 1 : t);
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
 // Kraskov
 // ---------------------------------------------------------------------------------------------------------
 // prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e   (MutualInformation.cpp:417-420)
-__global__ __launch_bounds__(64) void kraskov_prep_kernel(const float* __restrict__ ref, int cs,
-                                                          const double* __restrict__ noise_ref,
+__global__ __launch_bounds__(64) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                          int cs, const double* __restrict__ noise_ref,
                                                           double* __restrict__ prep) {
-    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = double(ref[e]) + noise_ref[e];
+    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = double(load_ref(src, members, e)) + noise_ref[e];
 }
 
 constexpr double kCountSlack = 1e-15;  // default_epsilon<double>::value, MutualInformation.cpp:163
@@ -425,7 +425,7 @@ int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 12
 
 }  // namespace
 
-hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                             const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
@@ -438,7 +438,7 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     const int n_pad = pad_pow2(cs);
     int* prep = reinterpret_cast<int*>(d_prep);
     const double* tableT = d_tables + (cs + 1);
-    hipLaunchKernelGGL(binned_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, n_pad, a.num_bins, a.min_ref, a.max_ref,
+    hipLaunchKernelGGL(binned_prep_kernel, dim3(1), dim3(64), 0, s, ref, d_members, cs, n_pad, a.num_bins, a.min_ref, a.max_ref,
                        tableT, prep);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
@@ -452,7 +452,7 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     return hipGetLastError();
 }
 
-hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref,
+hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
@@ -466,7 +466,7 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     double* prep = reinterpret_cast<double*>(d_prep);
-    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, noise_ref, prep);
+    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(64), 0, s, ref, d_members, cs, noise_ref, prep);
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     const size_t lds = size_t(3 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
     const int kk = a.k < cs - 1 ? a.k : cs - 1;

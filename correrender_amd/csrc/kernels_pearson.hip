@@ -16,26 +16,31 @@
 // load instruction covers 64*VPT consecutive floats of ONE member volume (256 B / 512 B / 1 KiB contiguous), all
 // cs loads of a wave are issued back to back before the first use, so a wave has cs*256*VPT bytes in flight.
 // No LDS, no MFMA: ~4 flop/byte, HBM-read bound.
-#include "crf_internal.h"
 #include <cstdlib>
+
+#include "crf_device.h"
+#include "crf_internal.h"
 
 namespace crf {
 
 // ---------------------------------------------------------------------------------------------------------
 // Reference-side preparation: one wave.  d_prep[e] = a_e for e < cs.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pearson_prep_kernel(const float* __restrict__ ref, int cs,
-                                                          float* __restrict__ prep) {
+__global__ __launch_bounds__(256) void pearson_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                           int cs, float* __restrict__ prep) {
+    extern __shared__ float x[];  // cs reference values
     __shared__ float sh[2];
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) x[e] = load_ref(src, members, e);
+    __syncthreads();
     const float n = float(cs);
     const float invN = 1.0f / n;
     const float invNm1 = 1.0f / (n - 1.0f);
     if (threadIdx.x == 0) {
         float meanX = 0.0f;
-        for (int e = 0; e < cs; e++) meanX += invN * ref[e];
+        for (int e = 0; e < cs; e++) meanX += invN * x[e];
         float varX = 0.0f;
         for (int e = 0; e < cs; e++) {
-            const float d = ref[e] - meanX;
+            const float d = x[e] - meanX;
             varX += invNm1 * d * d;
         }
         sh[0] = meanX;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(64) void pearson_prep_kernel(const float* __restric
     }
     __syncthreads();
     const float meanX = sh[0], sdX = sh[1];
-    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = invNm1 * ((ref[e] - meanX) / sdX);
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) prep[e] = invNm1 * ((x[e] - meanX) / sdX);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -217,7 +222,7 @@ hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const float* d_ref,
+hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxels, int max_vpt, const RefSource& ref,
                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           LaunchInfo* info) {
     if (cs == 1) {  // CorrelationCalculator.cpp:882-885
@@ -227,7 +232,7 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    hipLaunchKernelGGL(pearson_prep_kernel, dim3(1), dim3(64), 0, s, d_ref, cs, d_prep);
+    hipLaunchKernelGGL(pearson_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(float), s, ref, d_members, cs, d_prep);
 
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);

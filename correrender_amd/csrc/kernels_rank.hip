@@ -35,10 +35,13 @@ constexpr uint32_t kPadKey = 0xFFFFFFFFu;  // sorts after every real value (orde
 // Reference-side preparation
 // ---------------------------------------------------------------------------------------------------------
 // Spearman: prep[e] = a_e = invNm1 * ((rx_e - mean) / sd) over the reference RANKS rx (CorrelationCalculator.cpp:859-865).
-__global__ __launch_bounds__(256) void spearman_prep_kernel(const float* __restrict__ ref, int cs,
-                                                            float* __restrict__ prep) {
+__global__ __launch_bounds__(256) void spearman_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                            int cs, float* __restrict__ prep) {
+    __shared__ float ref[kMaxSortMembers];
     __shared__ float rx[kMaxSortMembers];
     __shared__ float sh[2];
+    for (int i = threadIdx.x; i < cs; i += blockDim.x) ref[i] = load_ref(src, members, i);
+    __syncthreads();
     for (int i = threadIdx.x; i < cs; i += blockDim.x) {
         const float v = ref[i];
         int s = 0;  // sum over j of sign(v_i - v_j); 2*rank_i = cs + 1 + s
@@ -69,10 +72,12 @@ __global__ __launch_bounds__(256) void spearman_prep_kernel(const float* __restr
 
 // Kendall: prep as int32: [0, N) perm (slot -> member), [N, 2N) gend (slot -> last slot of its x-tie group),
 // [2N] n1 = sum over x-tie groups t(t-1)/2 (computeTiesB, Correlation.cpp:305-329), [2N+1] 1 if x has ties.
-__global__ __launch_bounds__(256) void kendall_prep_kernel(const float* __restrict__ ref, int cs, int n_pad,
-                                                           int* __restrict__ prep) {
+__global__ __launch_bounds__(256) void kendall_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                           int cs, int n_pad, int* __restrict__ prep) {
+    __shared__ float ref[kMaxSortMembers];
     __shared__ int n1;
     if (threadIdx.x == 0) n1 = 0;
+    for (int i = threadIdx.x; i < cs; i += blockDim.x) ref[i] = load_ref(src, members, i);
     __syncthreads();
     for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
         if (i >= cs) {
@@ -265,7 +270,7 @@ int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 12
 
 }  // namespace
 
-hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref, float* d_prep,
+hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
                            float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
@@ -274,7 +279,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    hipLaunchKernelGGL(spearman_prep_kernel, dim3(1), dim3(256), 0, s, d_ref, cs, d_prep);
+    hipLaunchKernelGGL(spearman_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, d_prep);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -287,7 +292,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     return hipGetLastError();
 }
 
-hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const float* d_ref, float* d_prep,
+hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
@@ -298,7 +303,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     }
     const int n_pad = pad_pow2(cs);
     int* prep = reinterpret_cast<int*>(d_prep);
-    hipLaunchKernelGGL(kendall_prep_kernel, dim3(1), dim3(256), 0, s, d_ref, cs, n_pad, prep);
+    hipLaunchKernelGGL(kendall_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, n_pad, prep);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;

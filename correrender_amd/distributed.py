@@ -64,10 +64,18 @@ class ShardedCorrField:
             raise ValueError(f"rank {rank} of {world} owns no slice of a grid with zs={self.zs}")
         self.device = device if device is not None else torch.device("cpu")
         engine.set_grid(self.xs, self.ys, self.z_count, cs)
-        # two reference-vector buffers, alternated, so that a broadcast for step i+1 never overwrites the vector a
-        # still-running kernel of step i reads
-        self._ref = [torch.empty(cs, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self._flip = 0
+        # Reference-vector buffers, used round-robin.  prefetch() fills the next one on a side (communication) stream
+        # while the kernel of the current step still reads the previous one, so gather + broadcast of step i+1 overlap
+        # the evaluation of step i (independent reference points, e.g. successive mouse positions).
+        self._nbuf = 3
+        self._ref = [torch.empty(cs, dtype=torch.float32, device=self.device) for _ in range(self._nbuf)]
+        self._slot = 0
+        self._pending = []  # [(ref_xyz, slot)] prefetched, not yet consumed
+        self._cuda = self.device.type == "cuda"
+        if self._cuda:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+            self._ready = [torch.cuda.Event() for _ in range(self._nbuf)]   # vector landed in buffer[slot]
+            self._done = [None] * self._nbuf                                # last kernel that read buffer[slot]
         self._minmax = None
 
     @property
@@ -93,18 +101,54 @@ class ShardedCorrField:
             self._minmax = (mn, mx)
         return self._minmax
 
-    def compute(self, measure, out, ref_xyz, *, stream: int = 0, **kw):
-        """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats)."""
+    def _exchange(self, ref_xyz, buf, stream_ptr: int):
+        """owner: gather the cs reference values on the device; everyone: receive them (the one exchange step)."""
         x, y, z = ref_xyz
         owner, local_z = slab_owner(self.zs, self.world, z)
+        if self.rank == owner:
+            self.engine.gather_reference_device(x, y, local_z, buf, stream_ptr)
+        if self.world > 1:
+            self._dist.broadcast(buf, src=self._global_rank(owner), group=self.group)
+
+    def prefetch(self, ref_xyz):
+        """Starts gather + broadcast of the reference vector of a FUTURE compute(ref_xyz) on the communication stream.
+        Every rank must call prefetch/compute with the same sequence of reference points (collective semantics)."""
+        if len(self._pending) >= self._nbuf - 1:
+            raise RuntimeError("too many outstanding prefetches")
+        slot = self._slot
+        self._slot = (self._slot + 1) % self._nbuf
+        buf = self._ref[slot]
+        if self._cuda:
+            torch = self._torch
+            with torch.cuda.stream(self._comm_stream):
+                if self._done[slot] is not None:
+                    self._comm_stream.wait_event(self._done[slot])  # the kernel that last read this buffer
+                self._exchange(ref_xyz, buf, self._comm_stream.cuda_stream)
+                self._ready[slot].record(self._comm_stream)
+        else:
+            self._exchange(ref_xyz, buf, 0)
+        self._pending.append((tuple(ref_xyz), slot))
+
+    def compute(self, measure, out, ref_xyz, **kw):
+        """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats), on the
+        current torch stream, stream-ordered, without host synchronisation."""
         if int(measure) in _BINNED and "minmax_ref" not in kw:
             mm = self.global_minmax()
             kw = dict(kw, minmax_ref=mm, minmax_query=mm)
-        buf = self._ref[self._flip]
-        self._flip ^= 1
-        if self.rank == owner:
-            self.engine.gather_reference_device(x, y, local_z, buf, stream)
-        if self.world > 1:
-            self._dist.broadcast(buf, src=self._global_rank(owner), group=self.group)
-        self.engine.compute_device(measure, out, device_reference=buf, stream=stream, **kw)
+        if not self._pending or self._pending[0][0] != tuple(ref_xyz):
+            if self._pending:
+                raise RuntimeError("compute() must consume prefetched reference points in order")
+            self.prefetch(ref_xyz)
+        _, slot = self._pending.pop(0)
+        buf = self._ref[slot]
+        stream_ptr = 0
+        if self._cuda:
+            cur = self._torch.cuda.current_stream(self.device)
+            cur.wait_event(self._ready[slot])
+            stream_ptr = cur.cuda_stream
+        self.engine.compute_device(measure, out, device_reference=buf, stream=stream_ptr, **kw)
+        if self._cuda:
+            ev = self._torch.cuda.Event()
+            ev.record(cur)
+            self._done[slot] = ev
         return out

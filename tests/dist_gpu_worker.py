@@ -37,9 +37,13 @@ def main():
     bad = []
     for measure in (Measure.PEARSON, Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED,
                     Measure.MUTUAL_INFORMATION_KRASKOV):
-        for (x, y, z) in [(1, 2, 0), (12, 8, zs // 2), (23, 15, zs - 1)]:
+        points = [(1, 2, 0), (12, 8, zs // 2), (23, 15, zs - 1), (5, 5, 1)]
+        sharded.prefetch(points[0])                      # pipelined exchange: step i+1's broadcast overlaps step i
+        for pi, (x, y, z) in enumerate(points):
+            if pi + 1 < len(points):
+                sharded.prefetch(points[pi + 1])
             out = torch.empty(xs * ys * zl, dtype=torch.float32, device=dev)
-            sharded.compute(measure, out, (x, y, z), stream=stream, k=2)
+            sharded.compute(measure, out, (x, y, z), k=2)
             torch.cuda.synchronize()
             kw = dict(k=2, minmax_ref=gmm) if measure != Measure.PEARSON else {}
             want = oracle.field(int(measure), ens, ens[:, z, y, x].copy(), **kw)

@@ -61,8 +61,13 @@ def _worker(rank, world, port, zs, result_file):
         points = [(3, 4, 0), (5, 5, zs // 2), (11, 9, zs - 1), (0, 0, zs // 2 - 1), (6, 2, zs // 2)]
         for measure in (Measure.PEARSON, Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED,
                         Measure.MUTUAL_INFORMATION_KRASKOV):
-            for (x, y, z) in points:
+            pipelined = measure in (Measure.PEARSON, Measure.KENDALL)   # exercise prefetch() as well as plain compute()
+            if pipelined:
+                sharded.prefetch(points[0])
+            for pi, (x, y, z) in enumerate(points):
                 out = torch.empty(xs * ys * zl, dtype=torch.float32)
+                if pipelined and pi + 1 < len(points):
+                    sharded.prefetch(points[pi + 1])
                 sharded.compute(measure, out, (x, y, z), k=2)
                 gathered = [torch.empty(xs * ys * slab_bounds(zs, world, r)[1], dtype=torch.float32)
                             for r in range(world)] if rank == 0 else None
