@@ -1,0 +1,112 @@
+// Calculator.hpp -- host-side mirror of the reference's calculator plugin surface, restricted to what the
+// correlation-field path touches.  Same names, argument meaning and behaviour as
+//   class Calculator              /root/reference/src/Calculators/Calculator.hpp:86-138
+//   enum class FilterDevice       Calculator.hpp:79-81
+//   enum class CalculatorType     Calculator.hpp:57-63  (only CORRELATION is used here)
+//   class SettingsMap             /root/reference/src/Utils/InternalState.hpp:41-113
+// so that tests against this mirror read like tests against the reference classes, and so that the reference-side
+// subclass shown in INTEGRATION.md is a line-for-line transplant.  No rendering, GUI or Vulkan types.
+#pragma once
+#include <cstdint>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+namespace crfhost {
+
+enum class FieldType : uint32_t { SCALAR = 0 };
+enum class CalculatorType : uint32_t { CORRELATION = 10, INVALID = 16 };
+enum class FilterDevice { CPU, VULKAN, CUDA };
+
+// All values are strings; booleans accept "1"/"true" (InternalState.hpp:56-62).
+class SettingsMap {
+public:
+    SettingsMap() = default;
+    explicit SettingsMap(std::map<std::string, std::string> m) : settings(std::move(m)) {}
+    SettingsMap(std::initializer_list<std::pair<const std::string, std::string>> il) : settings(il) {}
+    void addKeyValue(const std::string& key, const std::string& value) { settings[key] = value; }
+    void addKeyValue(const std::string& key, const char* value) { settings[key] = value; }
+    void addKeyValue(const std::string& key, bool value) { settings[key] = value ? "1" : "0"; }
+    template <class T>
+    void addKeyValue(const std::string& key, const T& value) {
+        std::ostringstream os;
+        os << value;
+        settings[key] = os.str();
+    }
+    bool getValueOpt(const char* key, std::string& toset) const {
+        auto it = settings.find(key);
+        if (it == settings.end()) return false;
+        toset = it->second;
+        return true;
+    }
+    bool getValueOpt(const char* key, bool& toset) const {
+        auto it = settings.find(key);
+        if (it == settings.end()) return false;
+        toset = (it->second == "true") || (it->second == "1");
+        return true;
+    }
+    template <class T>
+    bool getValueOpt(const char* key, T& toset) const {
+        auto it = settings.find(key);
+        if (it == settings.end()) return false;
+        std::istringstream is(it->second);
+        is >> toset;
+        return true;
+    }
+    const std::map<std::string, std::string>& getMap() const { return settings; }
+
+private:
+    std::map<std::string, std::string> settings;
+};
+
+class VolumeData;
+
+// The reference reports errors through sgl::Logfile::get()->throwError (logs, then throws); here: an exception.
+struct CalculatorError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+class Calculator {
+public:
+    virtual ~Calculator() = default;
+    virtual void initialize() {}
+    void setCalculatorId(size_t id) { calculatorId = id; }
+    size_t getCalculatorId() const { return calculatorId; }
+    virtual bool getComputesCorrelation() const { return false; }
+    virtual CalculatorType getCalculatorType() const = 0;
+    virtual void setVolumeData(VolumeData* _volumeData, bool isNewData) { volumeData = _volumeData; (void)isNewData; }
+    void setIsDirty() { dirty = true; }
+    bool getIsDirty() { bool d = dirty; dirty = false; return d; }
+    bool getIsDirtyDontReset() const { return dirty; }
+    bool getHasNameChanged() { bool d = hasNameChanged; hasNameChanged = false; return d; }
+    bool getHasFilterDeviceChanged() { bool d = hasFilterDeviceChanged; hasFilterDeviceChanged = false; return d; }
+
+    virtual FieldType getOutputFieldType() { return FieldType::SCALAR; }
+    virtual std::string getOutputFieldName() = 0;
+    virtual FilterDevice getFilterDevice() = 0;
+    virtual bool getHasFixedRange() const { return false; }
+    virtual std::pair<float, float> getFixedRange() const { return {-1.0f, 1.0f}; }
+    virtual void setSettings(const SettingsMap&) {}
+    virtual void getSettings(SettingsMap&) {}
+
+    /// Writes the derived data to the output data of size VolumeData::xs*ys*zs (Calculator.hpp:123-124).
+    virtual void calculateCpu(int timeStepIdx, int ensembleIdx, float* buffer) {
+        (void)timeStepIdx; (void)ensembleIdx; (void)buffer;
+    }
+
+protected:
+    VolumeData* volumeData = nullptr;
+    bool dirty = false;
+    bool hasNameChanged = false;
+    bool hasFilterDeviceChanged = false;
+    size_t calculatorId = 0;
+    size_t calculatorConstructorUseCount = 0;
+};
+
+typedef std::shared_ptr<Calculator> CalculatorPtr;
+
+}  // namespace crfhost

@@ -1,0 +1,82 @@
+// VolumeData.hpp -- minimal host-side stand-in for the reference's field registry
+// (/root/reference/src/Volume/VolumeData.hpp:95-483, VolumeData.cpp), reproducing only the contract the correlation
+// calculators depend on:
+//   grid / ensemble getters                       VolumeData.hpp:167-171
+//   getFieldEntryCpu(type, name, t, e)            VolumeData.cpp:1202-1226: input fields come from storage; a field
+//       whose name belongs to a host calculator is produced by allocating `new float[xs*ys*zs]`, calling
+//       calc->calculateCpu(t, e, buffer) and wrapping the buffer in a HostCacheEntry that later delete[]s it
+//       (Cache/HostCacheEntry.hpp:39-50) -- the callee must neither retain nor free the buffer;
+//   getMinMaxScalarFieldValue(name, t, e)         VolumeData.cpp:1632-1670 (per (field,t,e) extrema, cached);
+//   addCalculator                                  VolumeData.cpp:1046-1086 (initialize, id, setVolumeData(this,true),
+//       registered under getOutputFieldName()).
+// No loaders, no device caches, no rendering: inputs are handed in as arrays.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "Calculator.hpp"
+
+namespace crfhost {
+
+class HostCacheEntryType {
+public:
+    HostCacheEntryType(size_t numEntries, float* dataOwned) : numEntries(numEntries), dataFloat(dataOwned) {}
+    ~HostCacheEntryType() { delete[] dataFloat; }
+    HostCacheEntryType(const HostCacheEntryType&) = delete;
+    HostCacheEntryType& operator=(const HostCacheEntryType&) = delete;
+    template <class T>
+    const T* data() const { return reinterpret_cast<const T*>(dataFloat); }
+    template <class T>
+    T dataAt(size_t idx) const { return T(dataFloat[idx]); }
+    size_t getNumEntries() const { return numEntries; }
+
+private:
+    size_t numEntries;
+    float* dataFloat;
+};
+typedef std::shared_ptr<HostCacheEntryType> HostCacheEntry;
+
+class VolumeData {
+public:
+    VolumeData(int xs, int ys, int zs, int ts, int es) : xs(xs), ys(ys), zs(zs), ts(ts), es(es) {}
+
+    int getGridSizeX() const { return xs; }
+    int getGridSizeY() const { return ys; }
+    int getGridSizeZ() const { return zs; }
+    int getTimeStepCount() const { return ts; }
+    int getEnsembleMemberCount() const { return es; }
+    size_t getSlice3dEntryCount() const { return size_t(xs) * size_t(ys) * size_t(zs); }
+    int getStandardScalarFieldIdx() const { return 0; }
+
+    /// Registers the data of one (field, time step, ensemble member): xs*ys*zs floats, copied.
+    void setFieldData(const std::string& fieldName, int timeStepIdx, int ensembleIdx, const float* values);
+    std::vector<std::string> getFieldNames(FieldType) const;
+
+    HostCacheEntry getFieldEntryCpu(FieldType fieldType, const std::string& fieldName, int timeStepIdx = -1,
+                                    int ensembleIdx = -1);
+    std::pair<float, float> getMinMaxScalarFieldValue(const std::string& fieldName, int timeStepIdx = -1,
+                                                      int ensembleIdx = -1);
+    void addCalculator(const CalculatorPtr& calculator);
+    /// Evicts the cached outputs of dirty calculators (the role of VolumeData::renderGuiCalculators, :1852-1936).
+    void updateCalculators();
+    size_t getNewCalculatorUseCount(CalculatorType) { return ++calculatorUseCount; }
+    /// Monotonic id of the input data (changes whenever setFieldData is called): lets a calculator keep a device copy.
+    uint64_t getDataGeneration() const { return dataGeneration; }
+
+private:
+    typedef std::tuple<std::string, int, int> Access;
+    int xs, ys, zs, ts, es;
+    std::vector<std::string> fieldNames;
+    std::map<Access, HostCacheEntry> storage;         // input fields
+    std::map<Access, HostCacheEntry> hostFieldCache;  // calculator outputs
+    std::map<Access, std::pair<float, float>> fieldMinMaxCache;
+    std::map<std::string, CalculatorPtr> calculatorsHost;
+    std::vector<CalculatorPtr> calculators;
+    size_t calculatorUseCount = 0;
+    uint64_t dataGeneration = 0;
+};
+
+}  // namespace crfhost

@@ -1,0 +1,180 @@
+// host_adapter_test.cpp -- driver used by tests/test_host_adapter.py.
+//   host_adapter_test settings                 CPU only: settings keys, defaults, naming, ranges, clamping
+//   host_adapter_test compute <in.bin> <dir>   GPU: runs scripted scenarios through VolumeData::getFieldEntryCpu ->
+//                                              CorrelationCalculator::calculateCpu and dumps the fields for the
+//                                              Python side to compare with the oracle.
+// in.bin: int32 xs, ys, zs, ts, es, nfields; then for field f, time t, member e: xs*ys*zs float32.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "CorrelationCalculator.hpp"
+
+using namespace crfhost;
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            std::exit(1);                                                            \
+        }                                                                            \
+    } while (0)
+
+static std::shared_ptr<VolumeData> makeVolume(int xs, int ys, int zs, int ts, int es, int nfields,
+                                              const std::vector<float>* data) {
+    auto vol = std::make_shared<VolumeData>(xs, ys, zs, ts, es);
+    const size_t n = size_t(xs) * ys * zs;
+    std::vector<float> zeros(n, 0.0f);
+    size_t off = 0;
+    for (int f = 0; f < nfields; f++)
+        for (int t = 0; t < ts; t++)
+            for (int e = 0; e < es; e++) {
+                vol->setFieldData(f == 0 ? "data" : "data" + std::to_string(f + 1), t, e,
+                                  data ? data->data() + off : zeros.data());
+                off += n;
+            }
+    return vol;
+}
+
+static int testSettings() {
+    auto vol = makeVolume(32, 24, 16, 1, 64, 1, nullptr);
+    auto calc = std::make_shared<CorrelationCalculator>(0);
+    vol->addCalculator(calc);
+    // defaults (CorrelationCalculator.hpp:206-212, CorrelationCalculator.cpp:104-110,592-598)
+    CHECK(calc->getCorrelationMeasureType() == CorrelationMeasureType::MUTUAL_INFORMATION_KRASKOV);
+    CHECK(calc->getOutputFieldName() == "Mutual Information (Kraskov)");
+    CHECK((calc->getReferencePoint() == std::array<int, 3>{16, 12, 8}));
+    CHECK(calc->getCorrelationMemberCount() == 64 && calc->getIsEnsembleMode());
+    CHECK(calc->getKraskovNumNeighbors() == 2 && calc->getKraskovNumNeighborsMax() == 20);  // ceil(192/100), max(ceil(448/100),20)
+    CHECK(calc->getFilterDevice() == FilterDevice::CPU && calc->getComputesCorrelation());
+    CHECK(!calc->getHasFixedRange());
+    // the canned state of src/Replicability/ReplicabilityState.hpp:40-60
+    SettingsMap state{{"calculate_absolute_value", "0"}, {"correlation_measure_type", "pearson"},
+                       {"correlation_mode", "Ensemble"}, {"data_mode", "Buffer Array"}, {"device", "CUDA"},
+                       {"fix_picking_z", "1"}, {"kmi_neighbors", "30"}, {"kraskov_estimator_index", "1"},
+                       {"mi_bins", "80"}, {"reference_point_x", "16"}, {"reference_point_y", "16"},
+                       {"reference_point_z", "16"}, {"scalar_field_idx", "0"}, {"use_buffer_tiling", "1"},
+                       {"use_separate_fields", "0"}};
+    calc->setSettings(state);
+    CHECK(calc->getIsDirtyDontReset());
+    CHECK(calc->getOutputFieldName() == "Pearson Correlation");
+    CHECK(calc->getHasFixedRange() && calc->getFixedRange() == std::make_pair(-1.0f, 1.0f));
+    SettingsMap out;
+    calc->getSettings(out);
+    const auto& m = out.getMap();
+    CHECK(m.at("correlation_measure_type") == "pearson" && m.at("device") == "CUDA");
+    CHECK(m.at("kmi_neighbors") == "30" && m.at("mi_bins") == "80" && m.at("kraskov_estimator_index") == "1");
+    CHECK(m.at("reference_point_x") == "16" && m.at("reference_point_y") == "16" && m.at("reference_point_z") == "16");
+    CHECK(m.at("correlation_mode") == "Ensemble" && m.at("calculate_absolute_value") == "0");
+    CHECK(m.at("scalar_field_idx") == "0" && m.at("correlation_field_mode") == "Single");
+    // every measure id round-trips and names follow CorrelationCalculator.hpp:156-165
+    const char* names[7] = {"Pearson Correlation", "Spearman Correlation", "Kendall Correlation",
+                            "Mutual Information (Binned)", "Mutual Information (Kraskov)",
+                            "Binned MI Correlation Coefficient", "KMI Correlation Coefficient"};
+    for (int i = 0; i < 7; i++) {
+        calc->setSettings(SettingsMap{{"correlation_measure_type", CORRELATION_MEASURE_TYPE_IDS[i]}});
+        CHECK(calc->getOutputFieldName() == names[i]);
+        SettingsMap o2;
+        calc->getSettings(o2);
+        CHECK(o2.getMap().at("correlation_measure_type") == CORRELATION_MEASURE_TYPE_IDS[i]);
+        const bool fixed = i != 3 && i != 4;
+        CHECK(calc->getHasFixedRange() == fixed);
+        if (i >= 5) CHECK(calc->getFixedRange() == std::make_pair(0.0f, 1.0f));
+    }
+    calc->setSettings(SettingsMap{{"kraskov_estimator_index", "7"}, {"device", "CPU"}, {"calculate_absolute_value", "true"},
+                                   {"correlation_measure_type", "kendall"}});
+    SettingsMap o3;
+    calc->getSettings(o3);
+    CHECK(o3.getMap().at("kraskov_estimator_index") == "2");  // clamped to [1,2], CorrelationCalculator.cpp:765
+    CHECK(o3.getMap().at("device") == "CPU" && o3.getMap().at("calculate_absolute_value") == "1");
+    CHECK(calc->getFixedRange() == std::make_pair(0.0f, 1.0f));  // abs flag reports [0,1] (CorrelationCalculator.hpp:173-184)
+    CHECK(!calc->getIsRealtime());
+    calc->setSettings(SettingsMap{{"device", "SomethingElse"}});  // unknown -> accelerator
+    SettingsMap o4;
+    calc->getSettings(o4);
+    CHECK(o4.getMap().at("device") == "Vulkan");
+    // reference point clamps to the grid and marks dirty (CorrelationCalculator.cpp:190-202)
+    (void)calc->getIsDirty();
+    calc->setReferencePoint({100, -5, 3});
+    CHECK((calc->getReferencePoint() == std::array<int, 3>{31, 0, 3}) && calc->getIsDirtyDontReset());
+    // second calculator of the same type gets a numbered name
+    auto calc2 = std::make_shared<CorrelationCalculator>(0);
+    vol->addCalculator(calc2);
+    CHECK(calc2->getOutputFieldName() == "Mutual Information (Kraskov) (2)");
+    // time mode is selected automatically when there is one member and several time steps (:85-91)
+    auto volT = makeVolume(8, 8, 4, 10, 1, 1, nullptr);
+    auto calcT = std::make_shared<CorrelationCalculator>(0);
+    volT->addCalculator(calcT);
+    CHECK(!calcT->getIsEnsembleMode() && calcT->getCorrelationMemberCount() == 10);
+    CHECK(calcT->getKraskovNumNeighbors() == 1);
+    std::puts("SETTINGS-OK");
+    return 0;
+}
+
+static void dump(const std::string& path, const float* v, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(v), std::streamsize(n * sizeof(float)));
+}
+
+static int testCompute(const char* inPath, const std::string& outDir) {
+    std::ifstream f(inPath, std::ios::binary);
+    int32_t h[6];
+    f.read(reinterpret_cast<char*>(h), sizeof h);
+    const int xs = h[0], ys = h[1], zs = h[2], ts = h[3], es = h[4], nf = h[5];
+    const size_t n = size_t(xs) * ys * zs;
+    std::vector<float> data(n * size_t(ts) * size_t(es) * size_t(nf));
+    f.read(reinterpret_cast<char*>(data.data()), std::streamsize(data.size() * sizeof(float)));
+    CHECK(bool(f));
+    auto vol = makeVolume(xs, ys, zs, ts, es, nf, &data);
+    auto calc = std::make_shared<CorrelationCalculator>(0);
+    vol->addCalculator(calc);
+    auto eval = [&](const std::string& tag, int t, int e) {
+        vol->updateCalculators();
+        HostCacheEntry entry = vol->getFieldEntryCpu(FieldType::SCALAR, calc->getOutputFieldName(), t, e);
+        CHECK(entry->getNumEntries() == n);
+        dump(outDir + "/" + tag + ".bin", entry->data<float>(), n);
+        // a second request is served from the host cache: same buffer, no recomputation
+        CHECK(vol->getFieldEntryCpu(FieldType::SCALAR, calc->getOutputFieldName(), t, e).get() == entry.get());
+    };
+    const int tFixed = ts > 1 && es > 1 ? 1 : 0;
+    for (int i = 0; i < 7; i++) {  // every measure at the default reference point (grid centre), default k
+        calc->setSettings(SettingsMap{{"correlation_measure_type", CORRELATION_MEASURE_TYPE_IDS[i]}});
+        eval(std::string("m_") + CORRELATION_MEASURE_TYPE_IDS[i], tFixed, 0);
+    }
+    calc->setSettings(SettingsMap{{"correlation_measure_type", "pearson"}});
+    calc->setReferencePoint({1, 2, 3});
+    eval("pearson_ref123", tFixed, 0);
+    calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_kraskov"}, {"kmi_neighbors", "3"},
+                                   {"kraskov_estimator_index", "2"}});
+    eval("kraskov2_k3_ref123", tFixed, 0);
+    if (nf > 1) {  // SEPARATE mode: reference vector from the second field (+ time lag when there are time steps)
+        calc->setSettings(SettingsMap{{"correlation_measure_type", "spearman"}, {"correlation_field_mode", "Separate"},
+                                       {"scalar_field_idx_ref", "1"}, {"scalar_field_idx_query", "0"}});
+        eval("spearman_separate", tFixed, 0);
+        calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_binned"}});
+        eval("binned_separate", tFixed, 0);
+        if (ts > 1) {
+            calc->setSettings(SettingsMap{{"correlation_measure_type", "pearson"}, {"use_time_lag_correlations", "1"},
+                                           {"time_lag_time_step_idx", "0"}});
+            eval("pearson_separate_lag0", tFixed, 0);
+        }
+    }
+    std::printf("COMPUTE-OK kernel_ms=%.4f\n", calc->getLastKernelTimeMs());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 2 && std::string(argv[1]) == "settings") return testSettings();
+        if (argc >= 4 && std::string(argv[1]) == "compute") return testCompute(argv[2], argv[3]);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    std::fprintf(stderr, "usage: host_adapter_test settings | compute <in.bin> <outdir>\n");
+    return 64;
+}

@@ -1,0 +1,79 @@
+"""The C++ host layer above the C ABI (correrender_amd/csrc/host): mirror of the reference's Calculator /
+VolumeData / CorrelationCalculator surface.  `settings` runs on CPU; `compute` needs the GPU and is compared with the
+oracle evaluated with the parameters the reference's calculateCpu would derive (CorrelationCalculator.cpp:781-866)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from correrender_amd import default_kraskov_k, synth
+from parity import assert_bit_exact, assert_close
+import oracle_lib
+
+ROOT = Path(__file__).resolve().parent.parent
+EXE = ROOT / "correrender_amd" / "host_adapter_test"
+
+
+def test_settings_defaults_naming_and_clamping():
+    r = subprocess.run([str(EXE), "settings"], capture_output=True, text=True)
+    assert r.returncode == 0 and "SETTINGS-OK" in r.stdout, r.stderr
+
+
+def _run_compute(tmp_path, data):
+    """data: float32 [nfields, ts, es, zs, ys, xs]"""
+    nf, ts, es, zs, ys, xs = data.shape
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        np.array([xs, ys, zs, ts, es, nf], np.int32).tofile(f)
+        np.ascontiguousarray(data, np.float32).tofile(f)
+    r = subprocess.run([str(EXE), "compute", str(inp), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "COMPUTE-OK" in r.stdout, r.stdout + r.stderr
+    return lambda tag: np.fromfile(tmp_path / f"{tag}.bin", np.float32)
+
+
+@pytest.mark.gpu
+def test_calculate_cpu_ensemble_mode(tmp_path, oracle):
+    xs, ys, zs, cs = 24, 16, 8, 32
+    a = synth.box_ensemble(xs, ys, zs, cs, seed=31)
+    b = synth.box_ensemble(xs, ys, zs, cs, seed=32)
+    # two time steps (t=1 is the one evaluated), two fields
+    data = np.stack([np.stack([a * 0.5 + 1.0, a]), np.stack([b, b * 2.0])])      # [nf=2, ts=2, es, z, y, x]
+    out = _run_compute(tmp_path, data)
+    ens = data[0, 1]
+    centre = (xs // 2, ys // 2, zs // 2)
+    refc = ens[:, centre[2], centre[1], centre[0]].copy()
+    mm = oracle.minmax(ens)
+    k = default_kraskov_k(cs)
+    assert_bit_exact(out("m_pearson"), oracle.field(oracle_lib.PEARSON, ens, refc), "adapter pearson")
+    assert_bit_exact(out("m_spearman"), oracle.field(oracle_lib.SPEARMAN, ens, refc), "adapter spearman")
+    assert_bit_exact(out("m_kendall"), oracle.field(oracle_lib.KENDALL, ens, refc), "adapter kendall")
+    assert_close(out("m_mi_binned"), oracle.field(oracle_lib.MI_BINNED, ens, refc, num_bins=80, minmax_ref=mm), "binned")
+    assert_close(out("m_binned_mi_correlation_coefficient"),
+                 oracle.field(oracle_lib.BINNED_MI_CC, ens, refc, num_bins=80, minmax_ref=mm), "binned cc")
+    assert_close(out("m_mi_kraskov"), oracle.field(oracle_lib.MI_KRASKOV, ens, refc, k=k), "kraskov")
+    assert_close(out("m_kmi_correlation_coefficient"), oracle.field(oracle_lib.KMI_CC, ens, refc, k=k), "kmi cc")
+    ref123 = ens[:, 3, 2, 1].copy()
+    assert_bit_exact(out("pearson_ref123"), oracle.field(oracle_lib.PEARSON, ens, ref123), "moved reference point")
+    assert_close(out("kraskov2_k3_ref123"), oracle.field(oracle_lib.MI_KRASKOV, ens, ref123, k=3, estimator=2), "ksg2")
+    # SEPARATE mode: reference vector from field 2 at the same time step; binned ranges per field (:820-846)
+    ens2 = data[1, 1]
+    ref_sep = ens2[:, 3, 2, 1].copy()
+    assert_bit_exact(out("spearman_separate"), oracle.field(oracle_lib.SPEARMAN, ens, ref_sep), "separate spearman")
+    assert_close(out("binned_separate"), oracle.field(oracle_lib.MI_BINNED, ens, ref_sep, num_bins=80,
+                                                      minmax_ref=oracle.minmax(ens2), minmax_query=mm), "separate binned")
+    ref_lag = data[1, 0][:, 3, 2, 1].copy()                                      # time-lag: field 2 at time step 0
+    assert_bit_exact(out("pearson_separate_lag0"), oracle.field(oracle_lib.PEARSON, ens, ref_lag), "time lag")
+
+
+@pytest.mark.gpu
+def test_calculate_cpu_time_mode(tmp_path, oracle):
+    """es = 1, ts = cs: the member axis is time (CorrelationCalculator.cpp:85-91,131-138)."""
+    xs, ys, zs, cs = 16, 12, 6, 20
+    a = synth.box_ensemble(xs, ys, zs, cs, seed=41)
+    data = a[None, :, None]                                                      # [nf=1, ts=cs, es=1, z, y, x]
+    out = _run_compute(tmp_path, data)
+    refc = a[:, zs // 2, ys // 2, xs // 2].copy()
+    assert_bit_exact(out("m_pearson"), oracle.field(oracle_lib.PEARSON, a, refc), "time-mode pearson")
+    assert_bit_exact(out("m_kendall"), oracle.field(oracle_lib.KENDALL, a, refc), "time-mode kendall")
+    assert_close(out("m_mi_kraskov"), oracle.field(oracle_lib.MI_KRASKOV, a, refc, k=default_kraskov_k(cs)), "time-mode ksg")
