@@ -135,6 +135,11 @@ class ShardedCorrField:
         if int(measure) in _BINNED and "minmax_ref" not in kw:
             mm = self.global_minmax()
             kw = dict(kw, minmax_ref=mm, minmax_query=mm)
+        if self.world == 1 and not self._pending:
+            # single GPU: no exchange; the gather is fused into the estimator's preparation kernel
+            stream_ptr = self._torch.cuda.current_stream(self.device).cuda_stream if self._cuda else 0
+            self.engine.compute_device(measure, out, tuple(ref_xyz), stream=stream_ptr, **kw)
+            return out
         if not self._pending or self._pending[0][0] != tuple(ref_xyz):
             if self._pending:
                 raise RuntimeError("compute() must consume prefetched reference points in order")

@@ -31,7 +31,8 @@ class OracleEngine:
     def compute_device(self, measure, out, ref=None, *, device_reference=None, stream=0, k=None,
                        kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
                        reference_values=None):
-        refv = device_reference.numpy().copy()
+        refv = (device_reference.numpy().copy() if device_reference is not None
+                else self.members[:, ref[2], ref[1], ref[0]].copy())
         kw = dict(k=k if k is not None else max(-(-3 * self.cs // 100), 1), estimator=kraskov_estimator_index,
                   num_bins=num_bins)
         if minmax_ref is not None:

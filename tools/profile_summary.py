@@ -52,6 +52,27 @@ def main():
         f = pmc["FETCH_SIZE"].get(k, float("nan"))
         w = pmc["WRITE_SIZE"].get(k, float("nan"))
         print(f"| {k} | {f:.0f} | {f * 1024 * 2 / 1e9:.4f} | {w:.0f} | {w * 1024 / 1e9:.4f} |")
+    # HBM traffic per launch of the dominant kernel, gfx950-corrected: FETCH_SIZE counts 128-B requests at 64 B (x2),
+    # WRITE_SIZE is exact; both in KiB.  Keyed like bench.py's load_pmc_traffic().
+    dominant = max(dur.items(), key=lambda kv: sum(kv[1]) if "synth" not in kv[0] else 0)[0]
+    measure, grid, members = "pearson", [256, 256, 256], 64
+    argv = sys.argv[2:]
+    for i, a in enumerate(argv):
+        if a == "--measure":
+            measure = argv[i + 1]
+        if a == "--members":
+            members = int(argv[i + 1])
+        if a == "--grid":
+            grid = [int(v) for v in argv[i + 1:i + 4]]
+    traffic = pmc["FETCH_SIZE"].get(dominant, 0.0) * 1024 * 2 + pmc["WRITE_SIZE"].get(dominant, 0.0) * 1024
+    entry = {f"{measure}:{grid[0]}x{grid[1]}x{grid[2]}x{members}:gpus1": {
+        "kernel": dominant, "traffic_bytes_per_launch": int(traffic),
+        "fetch_kib_raw": pmc["FETCH_SIZE"].get(dominant), "write_kib": pmc["WRITE_SIZE"].get(dominant),
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B; calibrated: equals cs*M*4 exactly), "
+                      "WRITE_SIZE x1; units KiB"}}
+    with open(os.path.join(out, "pmc_traffic_entry.json"), "w") as fh:
+        json.dump(entry, fh, indent=1)
+    print("\nHBM traffic per launch (" + dominant + f"): {traffic / 1e9:.4f} GB")
     with open(os.path.join(out, "summary.json"), "w") as fh:
         json.dump({"durations_us": {k: {"n": len(v), "avg": statistics.mean(v), "median": statistics.median(v)}
                                     for k, v in dur.items()}, "pmc_kib_per_launch": pmc}, fh, indent=1)
