@@ -7,6 +7,26 @@
 
 namespace crf {
 
+// Streaming member loads through buffer descriptors.  Member base pointers come out of a pointer table, so plain
+// loads are flat/global loads with a 64-bit VGPR address each (two VGPRs + a 64-bit VALU add per load in flight).  A
+// raw buffer load takes the wave-uniform base in a 128-bit SGPR descriptor and ONE shared 32-bit VGPR byte offset, and
+// the hardware bounds check (num_records) makes lanes past the end of the volume read 0 instead of faulting, so the
+// ragged tail needs no separate kernel.  aux = 2 is the non-temporal (`nt`) policy: every member value is read exactly
+// once per evaluation and the ensemble dwarfs the 256 MiB Infinity Cache.  A member volume (or slab) is < 4 GiB
+// (checked in crf_set_grid), so the 32-bit offset and num_records suffice.
+typedef int32_t __attribute__((ext_vector_type(4))) buffer_rsrc_t;
+constexpr int kAuxNonTemporal = 2;
+__device__ __forceinline__ auto make_member_rsrc(const float* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), /*stride*/ short(0), int(bytes), 0x00020000);
+}
+template <class RSRC>
+__device__ __forceinline__ float buffer_load_f32_nt(RSRC rsrc, uint32_t byte_offset) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int(byte_offset), 0, kAuxNonTemporal));
+}
+__device__ __forceinline__ float load_member_nt(const float* base, uint32_t bytes, uint32_t byte_offset) {
+    return buffer_load_f32_nt(make_member_rsrc(base, bytes), byte_offset);
+}
+
 __device__ __forceinline__ float load_ref(const RefSource& r, const float* const* __restrict__ members, int c) {
     return r.values ? r.values[c] : members[c][r.voxel];
 }
@@ -18,40 +38,63 @@ __device__ __forceinline__ uint32_t orderable_key(float f) {
     return b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-// Per-lane sorting networks over 64-bit composites held in registers (static indices only).
-#define CRF_CE(i, j)                       \
-    {                                      \
-        const uint64_t lo_ = a[i], hi_ = a[j]; \
-        const bool sw_ = hi_ < lo_;        \
-        a[i] = sw_ ? hi_ : lo_;            \
-        a[j] = sw_ ? lo_ : hi_;            \
+// Per-lane sorting networks over 64-bit (key, slot) composites held in registers (static indices only).
+//
+// A composite is built so that it is a POSITIVE NORMAL fp64 number whose numeric order equals the lexicographic
+// (key, slot) order:   bits = 0x4000000000000000 | (uint64(key32) << 29) | low        (low < 2^29; slot in bits 0..7)
+// bit 62 set and bit 61 clear keep the exponent field away from 0 (denormal) and 0x7FF (inf/NaN).  A compare-exchange
+// is then exactly two VALU instructions, v_min_f64 + v_max_f64 (they return one of their operands bit for bit),
+// instead of a 64-bit integer compare plus four conditional moves.  Inline asm because fmin()/fmax() add a
+// canonicalising v_max_f64 x, x per operand.
+typedef double composite_t;
+__device__ __forceinline__ composite_t make_composite(uint32_t key32, uint32_t low) {
+    const uint64_t bits = 0x4000000000000000ull | (uint64_t(key32) << 29) | uint64_t(low);
+    return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ uint32_t composite_key(composite_t c) {
+    return uint32_t(uint64_t(__double_as_longlong(c)) >> 29);
+}
+__device__ __forceinline__ uint32_t composite_low(composite_t c) {
+    return uint32_t(uint64_t(__double_as_longlong(c))) & 0x1FFFFFFFu;
+}
+__device__ __forceinline__ composite_t composite_or_low(composite_t c, uint32_t bits) {
+    return __longlong_as_double(__double_as_longlong(c) | (long long)bits);
+}
+
+#define CRF_CE(i, j)                                                               \
+    {                                                                              \
+        composite_t lo_, hi_;                                                      \
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(a[i]), "v"(a[j]));            \
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi_) : "v"(a[i]), "v"(a[j]));            \
+        a[i] = lo_;                                                                \
+        a[j] = hi_;                                                                \
     }
 template <int N>
 struct SortNet;
 template <>
 struct SortNet<16> {
-    static __device__ __forceinline__ void sort(uint64_t (&a)[16]) {
+    static __device__ __forceinline__ void sort(composite_t (&a)[16]) {
 #define CRF_SORTNET_N 16
 #include "sortnet.inc"
     }
 };
 template <>
 struct SortNet<32> {
-    static __device__ __forceinline__ void sort(uint64_t (&a)[32]) {
+    static __device__ __forceinline__ void sort(composite_t (&a)[32]) {
 #define CRF_SORTNET_N 32
 #include "sortnet.inc"
     }
 };
 template <>
 struct SortNet<64> {
-    static __device__ __forceinline__ void sort(uint64_t (&a)[64]) {
+    static __device__ __forceinline__ void sort(composite_t (&a)[64]) {
 #define CRF_SORTNET_N 64
 #include "sortnet.inc"
     }
 };
 template <>
 struct SortNet<128> {
-    static __device__ __forceinline__ void sort(uint64_t (&a)[128]) {
+    static __device__ __forceinline__ void sort(composite_t (&a)[128]) {
 #define CRF_SORTNET_N 128
 #include "sortnet.inc"
     }

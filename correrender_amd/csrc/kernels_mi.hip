@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     for (int i = lane; i <= N; i += 64) T[i] = i <= cs ? tableT[i] : 0.0;
     __syncthreads();
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const size_t vl = v < num_voxels ? v : num_voxels - 1;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
     const bool ref_all_valid = prep[N] != 0;
     const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + 4096);
 
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
 #pragma unroll
     for (int e = 0; e < N; e++) {
         if (EXACT || e < cs) {
-            const float y = members[e][vl];
+            const float y = load_member_nt(members[e], bytes, byte_offset);
             is_nan |= (y != y);
             const float q01 = (y - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
             const int b0 = prep[e];
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
     }
     for (int i = lane; i <= cs; i += 64) s_psi[i] = table_psi[i];
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const size_t vl = v < num_voxels ? v : num_voxels - 1;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
     bool is_nan = false;
 #pragma unroll 8
     for (int e = 0; e < cs; e++) {
-        const float y = members[e][vl];
+        const float y = load_member_nt(members[e], bytes, byte_offset);
         is_nan |= (y != y);
         s_y[e * 64 + lane] = y;
     }

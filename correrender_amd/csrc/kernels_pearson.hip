@@ -71,18 +71,23 @@ struct VecT<4> {
     using type = float __attribute__((ext_vector_type(4)));
 };
 
-// Member values are read exactly once per evaluation and the ensemble (4.3 GB at 256^3 x 64) is far larger than the
-// 256 MiB Infinity Cache, so the loads are issued non-temporal (`nt`): measured 0.753 -> 0.705 ms at 256^3 x 64
-// (5.79 -> 6.19 TB/s) on MI355X, profiles/tuning_r01.md.
+// VPT consecutive voxels of one member for this lane (see crf_device.h: buffer descriptor + shared 32-bit offset).
+// NT selects the non-temporal policy: measured 0.753 -> 0.705 ms at 256^3 x 64 on MI355X (profiles/tuning_r01.md).
 template <int VPT, bool NT>
-__device__ __forceinline__ void load_vec(const float* p, float (&dst)[VPT]) {
-    using V = typename VecT<VPT>::type;
-    V v;
-    if constexpr (NT)
-        v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
-    else
-        v = *reinterpret_cast<const V*>(p);
-    __builtin_memcpy(dst, &v, sizeof(V));
+__device__ __forceinline__ void load_vec(const float* base, uint32_t bytes, uint32_t byte_offset, float (&dst)[VPT]) {
+    const auto rsrc = make_member_rsrc(base, bytes);
+    constexpr int aux = NT ? kAuxNonTemporal : 0;
+    if constexpr (VPT == 1) {
+        dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int(byte_offset), 0, aux));
+    } else if constexpr (VPT == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, int(byte_offset), 0, aux);
+        dst[0] = __uint_as_float(v[0]);
+        dst[1] = __uint_as_float(v[1]);
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(byte_offset), 0, aux);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = __uint_as_float(v[i]);
+    }
 }
 template <int VPT>
 __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
@@ -95,13 +100,15 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
 template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES, int BLOCK = 256, bool NT = true>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
                                                                        const float* __restrict__ prep,
-                                                                       float* __restrict__ out, size_t voxel_offset,
+                                                                       float* __restrict__ out, uint32_t num_voxels,
                                                                        int cs) {
-    const size_t v0 = voxel_offset + (size_t(blockIdx.x) * BLOCK + threadIdx.x) * VPT;
+    const uint32_t v0 = (blockIdx.x * BLOCK + threadIdx.x) * VPT;
+    const uint32_t byte_offset = v0 * 4u;       // one 32-bit offset serves all cs loads of the lane
+    const uint32_t bytes = num_voxels * 4u;     // descriptor bound: lanes past the end read 0 and store nothing
     float y[CS_PAD][VPT];
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) load_vec<VPT, NT>(members[e] + v0, y[e]);
+        if (EXACT || e < cs) load_vec<VPT, NT>(members[e], bytes, byte_offset, y[e]);
     }
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
             for (int v = 0; v < VPT; v++) r[v] += a * (y[e][v] / sdY[v]);
         }
     }
-    store_vec<VPT>(out + v0, r);
+    if (v0 + VPT <= num_voxels) store_vec<VPT>(out + v0, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -183,30 +190,30 @@ __global__ void fill_kernel(float* __restrict__ out, size_t n, float value) {
 namespace {
 
 template <int CS_PAD, int VPT>
-void launch_reg(const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, int cs,
-                hipStream_t s) {
+void launch_reg(const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, size_t num_voxels,
+                int cs, hipStream_t s) {
     // occupancy request: data registers are CS_PAD*VPT per lane; ask for the waves/SIMD that budget allows.
     constexpr int kData = CS_PAD * VPT;
     constexpr int kMinWaves = kData <= 64 ? 4 : (kData <= 128 ? 2 : 1);
     if (cs == CS_PAD) {
         hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, true, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0, s,
-                           d_members, d_prep, d_out, size_t(0), cs);
+                           d_members, d_prep, d_out, uint32_t(num_voxels), cs);
     } else {
         hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, false, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0,
-                           s, d_members, d_prep, d_out, size_t(0), cs);
+                           s, d_members, d_prep, d_out, uint32_t(num_voxels), cs);
     }
 }
 
 template <int CS_PAD>
-void launch_reg_vpt(int vpt, const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, int cs,
-                    hipStream_t s) {
+void launch_reg_vpt(int vpt, const float* const* d_members, const float* d_prep, float* d_out, size_t blocks,
+                    size_t num_voxels, int cs, hipStream_t s) {
     if constexpr (CS_PAD * 4 <= 256) {
-        if (vpt == 4) return launch_reg<CS_PAD, 4>(d_members, d_prep, d_out, blocks, cs, s);
+        if (vpt == 4) return launch_reg<CS_PAD, 4>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
     }
     if constexpr (CS_PAD * 2 <= 256) {
-        if (vpt >= 2) return launch_reg<CS_PAD, 2>(d_members, d_prep, d_out, blocks, cs, s);
+        if (vpt >= 2) return launch_reg<CS_PAD, 2>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
     }
-    return launch_reg<CS_PAD, 1>(d_members, d_prep, d_out, blocks, cs, s);
+    return launch_reg<CS_PAD, 1>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
 }
 
 int env_int(const char* name, int fallback) {
@@ -251,11 +258,11 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
         if (variant > 0 && cs == 64) {  // tuning experiments (tools/tune_pearson.py), one voxel per lane
 #define CRF_VARIANT(MINW, BLK, NT_)                                                                              \
     {                                                                                                            \
-        const size_t blocks_ = num_voxels / BLK;                                                                 \
-        covered = blocks_ * BLK;                                                                                 \
+        const size_t blocks_ = (num_voxels + BLK - 1) / BLK;                                                     \
+        covered = num_voxels;                                                                                    \
         if (blocks_ > 0)                                                                                         \
             hipLaunchKernelGGL((pearson_reg_kernel<64, 1, true, MINW, BLK, NT_>), dim3(unsigned(blocks_)),       \
-                               dim3(BLK), 0, s, d_members, d_prep, d_out, size_t(0), cs);                        \
+                               dim3(BLK), 0, s, d_members, d_prep, d_out, uint32_t(num_voxels), cs);                        \
     }
             switch (variant) {
                 case 1: CRF_VARIANT(4, 256, false); break;  // temporal (default-policy) loads
@@ -268,18 +275,18 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
             goto tail;
         }
         const size_t per_block = size_t(256) * vpt;
-        const size_t blocks = num_voxels / per_block;
-        covered = blocks * per_block;
+        covered = num_voxels / vpt * vpt;                       // whole vectors; the descriptor bounds the last block
+        const size_t blocks = (covered + per_block - 1) / per_block;
         if (blocks > 0) {
             switch (cs_pad) {
-                case 16: launch_reg_vpt<16>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 32: launch_reg_vpt<32>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 48: launch_reg_vpt<48>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 64: launch_reg_vpt<64>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 96: launch_reg_vpt<96>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 128: launch_reg_vpt<128>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
-                default: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, cs, s); break;
+                case 16: launch_reg_vpt<16>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 32: launch_reg_vpt<32>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 48: launch_reg_vpt<48>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 64: launch_reg_vpt<64>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 96: launch_reg_vpt<96>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 128: launch_reg_vpt<128>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                default: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
             }
         }
         if (info) info->kernel_name = "pearson_reg_kernel";

@@ -117,22 +117,25 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     __shared__ uint16_t rank2[N * 64];
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const size_t vl = v < num_voxels ? v : num_voxels - 1;  // clamp: every load stays in bounds
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
 
-    uint64_t a[N];
+    composite_t a[N];
     bool is_nan = false;
 #pragma unroll
     for (int e = 0; e < N; e++) {
         if (EXACT || e < cs) {
-            float y = members[e][vl];
+            float y = load_member_nt(members[e], bytes, byte_offset);
             is_nan |= (y != y);
             y += 0.0f;  // -0.0 -> +0.0 so that key equality is float equality
-            a[e] = (uint64_t(orderable_key(y)) << 32) | uint32_t(e);
+            a[e] = make_composite(orderable_key(y), uint32_t(e));
         } else {
-            a[e] = (uint64_t(kPadKey) << 32) | uint32_t(e);
+            a[e] = make_composite(kPadKey, uint32_t(e));
         }
+        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
 
     // forward scan: first position of the tie run each sorted position belongs to, parked in bits 8..15 of the low word
     uint32_t run_start = 0;
@@ -140,11 +143,12 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     for (int p = 0; p < N; p++) {
         if (EXACT || p < cs) {
             if (p > 0) {
-                const bool same = uint32_t(a[p] >> 32) == uint32_t(a[p - 1] >> 32);
+                const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
                 run_start = same ? run_start : uint32_t(p);
             }
-            a[p] |= uint64_t(run_start << 8);
+            a[p] = composite_or_low(a[p], run_start << 8);
         }
+        if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the scheduler's window: register pressure
     }
     // backward scan: last position of the run; 2*rank = start + end + 2; scatter to the member's LDS row
     uint32_t run_end = 0;
@@ -152,14 +156,16 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     for (int p = N - 1; p >= 0; p--) {
         if (EXACT || p < cs) {
             bool same = false;
-            if (p < N - 1 && (EXACT || p + 1 < cs)) same = uint32_t(a[p] >> 32) == uint32_t(a[p + 1] >> 32);
+            if (p < N - 1 && (EXACT || p + 1 < cs)) same = composite_key(a[p]) == composite_key(a[p + 1]);
             run_end = same ? run_end : uint32_t(p);
-            const uint32_t low = uint32_t(a[p]);
+            const uint32_t low = composite_low(a[p]);
             const uint32_t slot = low & 0xFFu;
             const uint32_t start = (low >> 8) & 0xFFu;
             rank2[slot * 64 + lane] = uint16_t(start + run_end + 2u);
         }
+        if ((p & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ranks back in member order (same lane wrote them: program order suffices, no barrier)
     float r[N];
 #pragma unroll
@@ -179,27 +185,30 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     __shared__ uint8_t gend_lds[N];
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const size_t vl = v < num_voxels ? v : num_voxels - 1;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
     const bool x_ties = prep[2 * N + 1] != 0;  // wave-uniform
     if (x_ties) {
         for (int i = lane; i < N; i += 64) gend_lds[i] = uint8_t(prep[N + i]);
         __syncthreads();
     }
 
-    uint64_t a[N];
+    composite_t a[N];
     bool is_nan = false;
 #pragma unroll
     for (int e = 0; e < N; e++) {
         if (EXACT || e < cs) {
-            float y = members[prep[e]][vl];  // slot e = e-th smallest reference value
+            float y = load_member_nt(members[prep[e]], bytes, byte_offset);  // slot e = e-th smallest reference value
             is_nan |= (y != y);
             y += 0.0f;
-            a[e] = (uint64_t(orderable_key(y)) << 32) | uint32_t(e);
+            a[e] = make_composite(orderable_key(y), uint32_t(e));
         } else {
-            a[e] = (uint64_t(kPadKey) << 32) | uint32_t(e);
+            a[e] = make_composite(kPadKey, uint32_t(e));
         }
+        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
 
     constexpr int W = (N + 31) / 32;
     uint32_t seen[W];
@@ -211,11 +220,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
         if (EXACT || p < cs) {
             // ties in y: a run of t equal values contributes 0+1+...+(t-1) = t(t-1)/2
             if (p > 0) {
-                const bool same = uint32_t(a[p] >> 32) == uint32_t(a[p - 1] >> 32);
+                const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
                 run = same ? run + 1 : 0;
                 n2 += run;
             }
-            const uint32_t slot = uint32_t(a[p]) & 0xFFu;
+            const uint32_t slot = composite_low(a[p]) & 0xFFu;
             const uint32_t g = x_ties ? uint32_t(gend_lds[slot]) : slot;  // last slot with the same x
             // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
             const uint32_t gw = g >> 5;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
                 seen[w] |= (uint32_t(w) == sw) ? sbit : 0u;
             }
         }
+        if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
@@ -268,6 +278,12 @@ void launch_kendall_n(const float* const* d_members, const int* d_prep, float* d
 
 int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
 
+// waves/SIMD the 64-member kernels are compiled for (register cap 512/256/168); CRF_RANK_WAVES overrides for tuning.
+int env_waves(int fallback) {
+    const char* v = getenv("CRF_RANK_WAVES");
+    return (v && *v) ? atoi(v) : fallback;
+}
+
 }  // namespace
 
 hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
@@ -284,7 +300,13 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
         case 32: launch_spearman_n<32, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
-        case 64: launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+        case 64:
+            switch (env_waves(2)) {
+                case 1: launch_spearman_n<64, 1>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+                case 3: launch_spearman_n<64, 3>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+                default: launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+            }
+            break;
         default: launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s); break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -308,7 +330,13 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
         case 32: launch_kendall_n<32, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
-        case 64: launch_kendall_n<64, 2>(d_members, prep, d_out, num_voxels, cs, s); break;
+        case 64:
+            switch (env_waves(1)) {
+                case 3: launch_kendall_n<64, 3>(d_members, prep, d_out, num_voxels, cs, s); break;
+                case 2: launch_kendall_n<64, 2>(d_members, prep, d_out, num_voxels, cs, s); break;
+                default: launch_kendall_n<64, 1>(d_members, prep, d_out, num_voxels, cs, s); break;
+            }
+            break;
         default: launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s); break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
