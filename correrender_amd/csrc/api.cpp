@@ -48,6 +48,7 @@ struct crf_context {
     float* d_prep = nullptr;   // crf::kPrepBytes
     float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
     double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
+    uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
     uint32_t* d_minmax = nullptr;
     bool minmax_valid = false;
     float min_v = 0.f, max_v = 0.f;
@@ -215,6 +216,7 @@ void crf_destroy(crf_context* c) {
     if (c->d_prep) (void)hipFree(c->d_prep);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_todo) (void)hipFree(c->d_todo);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     for (auto& p : c->ev_pending) {
         (void)hipEventDestroy(p.first);
@@ -238,6 +240,8 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_todo) (void)hipFree(c->d_todo);
+    c->d_todo = nullptr;
     c->d_tables = nullptr;
     c->d_member_table = nullptr;
     c->d_ref = nullptr;
@@ -375,12 +379,18 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         case CRF_SPEARMAN:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
-            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, out, s, e0, e1, &info);
+            if (c->cs > 64 && !c->d_todo)
+                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
+            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
+                                     &info);
             break;
         case CRF_KENDALL:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
-            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, out, s, e0, e1, &info);
+            if (c->cs > 64 && !c->d_todo)
+                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
+            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
+                                    &info);
             break;
         case CRF_MI_BINNED:
         case CRF_BINNED_MI_CC: {

@@ -31,6 +31,15 @@ __device__ __forceinline__ float load_ref(const RefSource& r, const float* const
     return r.values ? r.values[c] : members[c][r.voxel];
 }
 
+// Compiler ordering fence on VALUES: an empty asm that "modifies" a and b makes everything computed from them
+// afterwards wait for both, which pins phase order in the fully unrolled straight-line kernels (the machine
+// scheduler otherwise hoists hundreds of independent address/mask computations and runs out of registers;
+// __builtin_amdgcn_sched_barrier does not stop IR-level and DAG-level reordering of pure register code).
+template <class A, class B>
+__device__ __forceinline__ void order_after(A& a, B& b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+}
+
 // Order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b) for non-NaN a, b; -0.0 must have been
 // canonicalised to +0.0 by the caller with `y + 0.0f` so that key equality == float equality).
 __device__ __forceinline__ uint32_t orderable_key(float f) {

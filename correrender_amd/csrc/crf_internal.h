@@ -44,12 +44,14 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
 hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s);
 
 // ---- kernels_rank.hip (Spearman, Kendall) ---------------------------------------------------------------
+// d_todo: num_voxels + 1 uint32 (count, then voxel indices) used by the split-sort kernels (64 < cs <= 128) to defer
+// voxels that contain ties to the monolithic kernel; may be null (then the monolithic kernel does everything).
 hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
-                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
-                           LaunchInfo* info);
+                           float* d_prep, uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                           hipEvent_t ev_end, LaunchInfo* info);
 hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
-                          float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
-                          LaunchInfo* info);
+                          float* d_prep, uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                          hipEvent_t ev_end, LaunchInfo* info);
 
 // ---- kernels_mi.hip (binned, Kraskov) -------------------------------------------------------------------
 struct BinnedArgs {

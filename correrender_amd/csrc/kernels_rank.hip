@@ -31,6 +31,13 @@ namespace crf {
 
 constexpr uint32_t kPadKey = 0xFFFFFFFFu;  // sorts after every real value (orderable_key(+inf) = 0xFF800000)
 
+// NaNs sort to the ends: a positive NaN has an orderable key above key(+inf) = 0xFF800000, a negative NaN one below
+// key(-inf) = 0x007FFFFF.  Looking at the smallest and the largest REAL key after the sort replaces a per-value
+// `y != y` test (which the compiler sinks to the end of the kernel, keeping every raw value alive in a register).
+__device__ __forceinline__ bool keys_hold_nan(uint32_t smallest_key, uint32_t largest_key) {
+    return smallest_key < 0x007FFFFFu || largest_key > 0xFF800000u;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Reference-side preparation
 // ---------------------------------------------------------------------------------------------------------
@@ -110,32 +117,41 @@ __global__ __launch_bounds__(256) void kendall_prep_kernel(RefSource src, const 
 // ---------------------------------------------------------------------------------------------------------
 // Spearman
 // ---------------------------------------------------------------------------------------------------------
+// `todo` == nullptr: lane = voxel blockIdx*64+lane.  `todo` != nullptr: the kernel walks the list todo[1 .. 1+todo[0])
+// of voxel indices (voxels a fast kernel deferred because they contain ties) with a grid-stride loop.
 template <int N, bool EXACT, int MIN_WAVES>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* const* __restrict__ members,
                                                                  const float* __restrict__ prep,
-                                                                 float* __restrict__ out, size_t num_voxels, int cs) {
+                                                                 float* __restrict__ out, size_t num_voxels, int cs,
+                                                                 const uint32_t* __restrict__ todo) {
     __shared__ uint16_t rank2[N * 64];
     const int lane = threadIdx.x;
-    const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const uint32_t count = todo ? todo[0] : 0u;
+    for (uint32_t base = blockIdx.x * 64u; todo == nullptr || base < count; base += gridDim.x * 64u) {
+    const uint32_t item = base + lane;
+    const bool active = todo ? item < count : item < num_voxels;
+    const size_t v = todo ? (active ? todo[1 + item] : num_voxels) : item;
+    const uint32_t byte_offset = uint32_t(v) * 4u;  // inactive lanes are out of range: they read 0 and store nothing
 
     composite_t a[N];
-    bool is_nan = false;
+    {
+        float y[N];  // all loads are issued before the first use (unconditional: slots past cs re-read the last member)
 #pragma unroll
-    for (int e = 0; e < N; e++) {
-        if (EXACT || e < cs) {
-            float y = load_member_nt(members[e], bytes, byte_offset);
-            is_nan |= (y != y);
-            y += 0.0f;  // -0.0 -> +0.0 so that key equality is float equality
-            a[e] = make_composite(orderable_key(y), uint32_t(e));
-        } else {
-            a[e] = make_composite(kPadKey, uint32_t(e));
+        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[EXACT ? e : (e < cs ? e : cs - 1)], bytes, byte_offset);
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const float yc = y[e] + 0.0f;  // -0.0 -> +0.0 so that key equality is float equality
+            a[e] = make_composite((EXACT || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
         }
-        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
+    bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
+#pragma unroll
+    for (int p = 0; p < N; p++)
+        if (EXACT ? p == N - 1 : p == cs - 1) is_nan |= composite_key(a[p]) > 0xFF800000u;
 
     // forward scan: first position of the tie run each sorted position belongs to, parked in bits 8..15 of the low word
     uint32_t run_start = 0;
@@ -172,7 +188,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     for (int e = 0; e < N; e++) r[e] = (EXACT || e < cs) ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
     float res = pearson_tail<N, EXACT>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) out[v] = res;
+    if (active) out[v] = res;
+    if (todo == nullptr) break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -181,61 +199,74 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
 template <int N, bool EXACT, int MIN_WAVES>
 __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* const* __restrict__ members,
                                                                 const int* __restrict__ prep, float* __restrict__ out,
-                                                                size_t num_voxels, int cs) {
+                                                                size_t num_voxels, int cs,
+                                                                const uint32_t* __restrict__ todo) {
     __shared__ uint8_t gend_lds[N];
     const int lane = threadIdx.x;
-    const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const bool x_ties = prep[2 * N + 1] != 0;  // wave-uniform
     if (x_ties) {
         for (int i = lane; i < N; i += 64) gend_lds[i] = uint8_t(prep[N + i]);
         __syncthreads();
     }
+    const uint32_t count = todo ? todo[0] : 0u;
+    for (uint32_t base = blockIdx.x * 64u; todo == nullptr || base < count; base += gridDim.x * 64u) {
+    const uint32_t item = base + lane;
+    const bool active = todo ? item < count : item < num_voxels;
+    const size_t v = todo ? (active ? todo[1 + item] : num_voxels) : item;
+    const uint32_t byte_offset = uint32_t(v) * 4u;
 
     composite_t a[N];
-    bool is_nan = false;
+    {
+        float y[N];  // slot e = e-th smallest reference value (prep[e] = member index; pads point at member 0)
 #pragma unroll
-    for (int e = 0; e < N; e++) {
-        if (EXACT || e < cs) {
-            float y = load_member_nt(members[prep[e]], bytes, byte_offset);  // slot e = e-th smallest reference value
-            is_nan |= (y != y);
-            y += 0.0f;
-            a[e] = make_composite(orderable_key(y), uint32_t(e));
-        } else {
-            a[e] = make_composite(kPadKey, uint32_t(e));
+        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[prep[e]], bytes, byte_offset);
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const float yc = y[e] + 0.0f;
+            a[e] = make_composite((EXACT || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
         }
-        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
-
-    constexpr int W = (N + 31) / 32;
-    uint32_t seen[W];
+    bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
 #pragma unroll
-    for (int w = 0; w < W; w++) seen[w] = 0u;
+    for (int p = 0; p < N; p++)
+        if (EXACT ? p == N - 1 : p == cs - 1) is_nan |= composite_key(a[p]) > 0xFF800000u;
+
+    constexpr int W = (N + 63) / 64;
+    uint64_t seen[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) seen[w] = 0ull;
     int32_t discordant = 0, n2 = 0, run = 0;
+    uint32_t prev_key = 0;
 #pragma unroll
     for (int p = 0; p < N; p++) {
         if (EXACT || p < cs) {
             // ties in y: a run of t equal values contributes 0+1+...+(t-1) = t(t-1)/2
+            const uint32_t key = composite_key(a[p]);
             if (p > 0) {
-                const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
-                run = same ? run + 1 : 0;
+                run = (key == prev_key) ? run + 1 : 0;
                 n2 += run;
             }
-            const uint32_t slot = composite_low(a[p]) & 0xFFu;
+            prev_key = key;
+            uint32_t slot = composite_low(a[p]) & 0xFFu;
+            if ((p & 3) == 0) order_after(slot, seen[0]);  // keep the N mask computations from being hoisted en bloc
             const uint32_t g = x_ties ? uint32_t(gend_lds[slot]) : slot;  // last slot with the same x
             // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
-            const uint32_t gw = g >> 5;
-            const uint32_t gm = 0xFFFFFFFEu << (g & 31u);
-            const uint32_t sw = slot >> 5;
-            const uint32_t sbit = 1u << (slot & 31u);
+            if constexpr (W == 1) {
+                discordant += __popcll(seen[0] & (0xFFFFFFFFFFFFFFFEull << g));
+                seen[0] |= 1ull << slot;
+            } else {
+                const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
+                const uint64_t sbit = 1ull << (slot & 63u);
 #pragma unroll
-            for (int w = 0; w < W; w++) {
-                const uint32_t mask = (uint32_t(w) > gw) ? 0xFFFFFFFFu : ((uint32_t(w) == gw) ? gm : 0u);
-                discordant += __popc(seen[w] & mask);
-                seen[w] |= (uint32_t(w) == sw) ? sbit : 0u;
+                for (int w = 0; w < W; w++) {
+                    const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
+                    discordant += __popcll(seen[w] & mask);
+                    seen[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
+                }
             }
         }
         if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -247,33 +278,273 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2));
     float res = float(numerator) / denominator;
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) out[v] = res;
+    if (active) out[v] = res;
+    if (todo == nullptr) break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 64 < cs <= 128: split-sort kernels.
+//
+// 128 (key, slot) composites are 256 VGPRs: the monolithic kernels above then run one wave per SIMD with the overflow
+// in AGPRs/scratch, and a lone wave issues fp32/integer VALU at half rate.  Here the voxel's values are handled as two
+// chunks of 64 (A = slots 0..63, B = slots 64..cs-1), each sorted on its own in 128 VGPRs; A's sorted keys are parked
+// in the lane's LDS column and every element of B finds its position among them by a 7-probe binary search, which
+// gives all cross-chunk order information (rank of b in the union = own position + #{A < b}; the A side follows from
+// a per-lane histogram of those positions and a prefix sum).  Peak ~175 VGPRs and 16 KB LDS per wave: two waves per
+// SIMD.  The kernels handle TIE-FREE voxels only (the overwhelmingly common case for continuous data); a voxel with
+// two equal values is appended to a todo list that the monolithic kernel then walks.
+// ---------------------------------------------------------------------------------------------------------
+// number of keys in the lane's sorted LDS column (stride 64 dwords) that are < key.  `tie_min` keeps the running
+// minimum of (k ^ key) over the probed lower-bound elements: it reaches 0 iff some key of the column equals `key`
+// (two VALU ops, no lane-mask bookkeeping).
+__device__ __forceinline__ uint32_t lower_bound_64(const uint32_t* col, uint32_t key, uint32_t& tie_min) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) pos += (col[(pos + uint32_t(s) - 1u) * 64u] < key) ? uint32_t(s) : 0u;
+    const uint32_t k = col[pos * 64u];
+    tie_min = min(tie_min, k ^ key);
+    return pos + ((k < key) ? 1u : 0u);
+}
+
+// loads slots base..base+63 of the lane's voxel as composites (low word = slot - base), pads beyond cs
+template <bool EXACT, bool PERMUTED>
+__device__ __forceinline__ void load_chunk_64(composite_t (&a)[64], const float* const* __restrict__ members,
+                                              const int* __restrict__ perm, int base, int cs, uint32_t bytes,
+                                              uint32_t byte_offset) {
+    float y[64];  // all loads first (unconditional: slots past cs re-read a valid member), then the conversion
+#pragma unroll
+    for (int e = 0; e < 64; e++) {
+        const int slot = (EXACT || base + e < cs) ? base + e : cs - 1;
+        y[e] = load_member_nt(PERMUTED ? members[perm[slot]] : members[slot], bytes, byte_offset);
+    }
+#pragma unroll
+    for (int e = 0; e < 64; e++) {
+        const float yc = y[e] + 0.0f;
+        a[e] = make_composite((EXACT || base + e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
+    }
+}
+
+template <bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void spearman_split128_kernel(const float* const* __restrict__ members,
+                                                                          const float* __restrict__ prep,
+                                                                          float* __restrict__ out, size_t num_voxels,
+                                                                          int cs, uint32_t* __restrict__ todo) {
+    __shared__ uint32_t lds[64 * 64];  // phase 1-3: sorted keys of chunk A [q][lane]; afterwards positions + histogram
+    __shared__ uint8_t slotA[64 * 64];  // slot (0..63) of the q-th smallest element of chunk A, [q][lane]
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const bool active = v < num_voxels;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const int nB = cs - 64;
+    bool is_nan = false;
+    uint32_t tie_min = 0xFFFFFFFFu;  // min over compared key pairs of (k1 ^ k2): 0 iff the voxel has a tie
+    uint32_t infoB[64];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
+    {
+        composite_t a[64];
+        load_chunk_64<true, false>(a, members, nullptr, 0, cs, bytes, byte_offset);
+        __builtin_amdgcn_sched_barrier(0);
+        SortNet<64>::sort(a);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t prev = 0;
+#pragma unroll
+        for (int q = 0; q < 64; q++) {
+            const uint32_t key = composite_key(a[q]);
+            if (q > 0) tie_min = min(tie_min, key ^ prev);
+            if (q == 0) is_nan |= key < 0x007FFFFFu;
+            if (q == 63) is_nan |= key > 0xFF800000u;
+            prev = key;
+            lds[q * 64 + lane] = key;
+            slotA[q * 64 + lane] = uint8_t(composite_low(a[q]) & 0xFFu);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t byte_offset_b = byte_offset;
+    order_after(tie_min, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
+    {
+        composite_t b[64];
+        load_chunk_64<EXACT, false>(b, members, nullptr, 64, cs, bytes, byte_offset_b);
+        __builtin_amdgcn_sched_barrier(0);
+        SortNet<64>::sort(b);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t prev = 0;
+#pragma unroll
+        for (int p = 0; p < 64; p++) {
+            infoB[p] = 0u;
+            if (EXACT || p < nB) {
+                const uint32_t key = composite_key(b[p]);
+                if (p > 0) tie_min = min(tie_min, key ^ prev);
+                if (p == 0) is_nan |= key < 0x007FFFFFu;
+                if (EXACT ? p == 63 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                prev = key;
+                const uint32_t less = lower_bound_64(&lds[lane], key, tie_min);  // #{A < b_p}, 0..64
+                infoB[p] = less | ((composite_low(b[p]) & 0xFFu) << 8);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // LDS is re-used from here on (this lane's binary searches are complete; LDS operations of a wave stay in order)
+    uint8_t* pos_of = reinterpret_cast<uint8_t*>(lds);  // [slot 0..127][lane]: 0-based position in the union
+    uint8_t* hist = pos_of + 128 * 64;                  // [0..64][lane]: #{b : #{A < b} == t}
+#pragma unroll
+    for (int t = 0; t <= 64; t++) hist[t * 64 + lane] = 0;
+#pragma unroll
+    for (int p = 0; p < 64; p++) {
+        if (EXACT || p < nB) {
+            const uint32_t less = infoB[p] & 0xFFu;
+            const uint32_t slot = infoB[p] >> 8;
+            const uint32_t h = hist[less * 64 + lane];
+            hist[less * 64 + lane] = uint8_t(h + 1u);
+            pos_of[(64 + slot) * 64 + lane] = uint8_t(uint32_t(p) + less);
+        }
+    }
+    uint32_t below = 0;  // #{B < a_q} = #{b : #{A < b} <= q} (no ties)
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+        below += uint32_t(hist[q * 64 + lane]);
+        pos_of[uint32_t(slotA[q * 64 + lane]) * 64 + lane] = uint8_t(uint32_t(q) + below);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float r[128];
+#pragma unroll
+    for (int e = 0; e < 128; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
+    float res = pearson_tail<128, EXACT>(r, prep, cs);
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (active) {
+        if (tie_min == 0u && !is_nan) {
+            todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        } else {
+            out[v] = res;
+        }
+    }
+}
+
+// discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..63), two-word bitset
+__device__ __forceinline__ int32_t chunk_inversions_64(const composite_t (&a)[64], int count, bool exact) {
+    uint64_t seen = 0ull;
+    int32_t inv = 0;
+#pragma unroll
+    for (int p = 0; p < 64; p++) {
+        if (exact || p < count) {
+            uint32_t slot = composite_low(a[p]) & 0xFFu;
+            if ((p & 3) == 0) order_after(slot, seen);  // keep the 64 mask computations from being hoisted en bloc
+            inv += __popcll(seen & (0xFFFFFFFFFFFFFFFEull << slot));  // already-seen slots above this one
+            seen |= 1ull << slot;
+        }
+    }
+    return inv;
+}
+
+template <bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void kendall_split128_kernel(const float* const* __restrict__ members,
+                                                                         const int* __restrict__ prep,
+                                                                         float* __restrict__ out, size_t num_voxels,
+                                                                         int cs, uint32_t* __restrict__ todo) {
+    __shared__ uint32_t keysA[64 * 64];
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const bool active = v < num_voxels;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const int nB = cs - 64;
+    const bool x_ties = prep[2 * 128 + 1] != 0;  // x-tie groups may straddle the chunks: left to the monolithic kernel
+    if (x_ties) {
+        if (active) todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        return;
+    }
+    bool is_nan = false;
+    uint32_t tie_min = 0xFFFFFFFFu;
+    int32_t discordant = 0;
+    {
+        composite_t a[64];
+        load_chunk_64<true, true>(a, members, prep, 0, cs, bytes, byte_offset);
+        __builtin_amdgcn_sched_barrier(0);
+        SortNet<64>::sort(a);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t prev = 0;
+#pragma unroll
+        for (int q = 0; q < 64; q++) {
+            const uint32_t key = composite_key(a[q]);
+            if (q > 0) tie_min = min(tie_min, key ^ prev);
+            if (q == 0) is_nan |= key < 0x007FFFFFu;
+            if (q == 63) is_nan |= key > 0xFF800000u;
+            prev = key;
+            keysA[q * 64 + lane] = key;
+        }
+        discordant += chunk_inversions_64(a, 64, true);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t byte_offset_b = byte_offset;
+    order_after(discordant, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
+    order_after(tie_min, byte_offset_b);
+    {
+        composite_t b[64];
+        load_chunk_64<EXACT, true>(b, members, prep, 64, cs, bytes, byte_offset_b);
+        __builtin_amdgcn_sched_barrier(0);
+        SortNet<64>::sort(b);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t prev = 0;
+#pragma unroll
+        for (int p = 0; p < 64; p++) {
+            if (EXACT || p < nB) {
+                const uint32_t key = composite_key(b[p]);
+                if (p > 0) tie_min = min(tie_min, key ^ prev);
+                if (p == 0) is_nan |= key < 0x007FFFFFu;
+                if (EXACT ? p == 63 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                prev = key;
+                // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
+                discordant += 64 - int32_t(lower_bound_64(&keysA[lane], key, tie_min));
+            }
+        }
+        discordant += chunk_inversions_64(b, nB, EXACT);
+    }
+    const int32_t n = cs;
+    const int32_t n0 = (n * (n - 1)) / 2;
+    const int32_t n1 = prep[2 * 128];  // 0 here
+    const int32_t numerator = n0 - n1 - 2 * discordant;  // n2 = 0: no ties in y
+    const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
+    float res = float(numerator) / denominator;
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (active) {
+        if (tie_min == 0u && !is_nan) {
+            todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        } else {
+            out[v] = res;
+        }
+    }
 }
 
 namespace {
 
+// tuning switches (tools/tune_pearson.py): CRF_RANK_EXACT=0 forces the guarded instantiations
+bool env_exact() {
+    const char* v = getenv("CRF_RANK_EXACT");
+    return !(v && *v == '0');
+}
+
+constexpr unsigned kTodoBlocks = 2048;  // grid of the list-walking pass (grid-stride over the deferred voxels)
+
 template <int N, int MIN_WAVES>
 void launch_spearman_n(const float* const* d_members, const float* d_prep, float* d_out, size_t num_voxels, int cs,
-                       hipStream_t s) {
-    const unsigned blocks = unsigned((num_voxels + 63) / 64);
-    if (cs == N)
+                       hipStream_t s, const uint32_t* todo = nullptr) {
+    const unsigned blocks = todo ? kTodoBlocks : unsigned((num_voxels + 63) / 64);
+    if (cs == N && env_exact())
         hipLaunchKernelGGL((spearman_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs);
+                           d_out, num_voxels, cs, todo);
     else
         hipLaunchKernelGGL((spearman_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs);
+                           d_out, num_voxels, cs, todo);
 }
 
 template <int N, int MIN_WAVES>
 void launch_kendall_n(const float* const* d_members, const int* d_prep, float* d_out, size_t num_voxels, int cs,
-                      hipStream_t s) {
-    const unsigned blocks = unsigned((num_voxels + 63) / 64);
-    if (cs == N)
+                      hipStream_t s, const uint32_t* todo = nullptr) {
+    const unsigned blocks = todo ? kTodoBlocks : unsigned((num_voxels + 63) / 64);
+    if (cs == N && env_exact())
         hipLaunchKernelGGL((kendall_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs);
+                           d_out, num_voxels, cs, todo);
     else
         hipLaunchKernelGGL((kendall_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs);
+                           d_out, num_voxels, cs, todo);
 }
 
 int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
@@ -287,7 +558,9 @@ int env_waves(int fallback) {
 }  // namespace
 
 hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
-                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+                           uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                           LaunchInfo* info) {
+    bool split = false;
     if (cs == 1) {
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
@@ -307,15 +580,34 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                 default: launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s); break;
             }
             break;
-        default: launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+        default:
+            // measured at 256^3 x 128 (profiles/tuning_r01.md): split 5.1 ms (unguarded) / 7.4 ms (guarded) vs
+            // monolithic 7.5 ms / 19 ms
+            if (d_todo && env_waves(2) != 0) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                if (cs == 128 && env_exact())
+                    hipLaunchKernelGGL((spearman_split128_kernel<true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((spearman_split128_kernel<false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
+                launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
+                split = true;
+            } else {
+                launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s);
+            }
+            break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info) info->kernel_name = "spearman_kernel";
+    if (info) info->kernel_name = split ? "spearman_split128_kernel" : "spearman_kernel";
     return hipGetLastError();
 }
 
 hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
-                          float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+                          uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
+                          LaunchInfo* info) {
+    bool split = false;
     if (cs == 1) {
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
@@ -337,10 +629,27 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                 default: launch_kendall_n<64, 1>(d_members, prep, d_out, num_voxels, cs, s); break;
             }
             break;
-        default: launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s); break;
+        default:
+            if (d_todo && env_waves(2) != 0) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                // the guarded instantiation compiles to 226 VGPRs without scratch and is the fastest for every cs
+                // (4.8 ms at 256^3 x 128 vs 12.8 ms unguarded, 13.9-27.7 ms monolithic)
+                if (cs == 128 && env_exact() && getenv("CRF_RANK_EXACT"))
+                    hipLaunchKernelGGL((kendall_split128_kernel<true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((kendall_split128_kernel<false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       prep, d_out, num_voxels, cs, d_todo);
+                launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
+                split = true;
+            } else {
+                launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s);
+            }
+            break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info) info->kernel_name = "kendall_kernel";
+    if (info) info->kernel_name = split ? "kendall_split128_kernel" : "kendall_kernel";
     return hipGetLastError();
 }
 
