@@ -229,18 +229,59 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
 // ---------------------------------------------------------------------------------------------------------
 // Kraskov
 // ---------------------------------------------------------------------------------------------------------
-// prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e   (MutualInformation.cpp:417-420)
-__global__ __launch_bounds__(64) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
-                                                          int cs, const double* __restrict__ noise_ref,
-                                                          double* __restrict__ prep) {
-    for (int e = threadIdx.x; e < cs; e += 64) prep[e] = double(load_ref(src, members, e)) + noise_ref[e];
+// prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e (MutualInformation.cpp:417-420), member order;
+//                   [cs, 2cs) the same values sorted ascending (the reference sorts them for its 1-D range counts,
+//                   MutualInformation.cpp:187; voxel independent, so sorted once per evaluation)
+__global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                           int cs, const double* __restrict__ noise_ref,
+                                                           double* __restrict__ prep) {
+    __shared__ double px[256];
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) px[e] = double(load_ref(src, members, e)) + noise_ref[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) {
+        const double v = px[e];
+        int rank = 0;
+        for (int j = 0; j < cs; j++) rank += (px[j] < v || (px[j] == v && j < e)) ? 1 : 0;
+        prep[e] = v;
+        prep[cs + rank] = v;
+    }
 }
 
 constexpr double kCountSlack = 1e-15;  // default_epsilon<double>::value, MutualInformation.cpp:163
-constexpr int kTI = 4;                 // points whose k-select runs concurrently per lane
 
-// KP1 > 0: k+1 = KP1 kept distances in registers.  KP1 == 0: any k, selection by repeated minimum passes.
-template <int KP1>
+// fp64 min / max / Chebyshev distance as single instructions.  fmin()/fmax() make hipcc canonicalise each operand first
+// (an extra v_max_f64 x, x); the operands here are never signalling NaNs and the k-select only needs "one of the two".
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double chebyshev_f64(double dx, double dy) {  // max(|dx|, |dy|)
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(dx), "v"(dy));
+    return r;
+}
+
+// #{ t : tab[t] < v } for an ascending table of n entries; top = largest power of two <= n.  Branch-free binary search;
+// the table is shared by the wave (LDS), the probe index is per lane.
+__device__ __forceinline__ int count_less(const double* tab, int n, int top, double v) {
+    int pos = 0;
+    for (int step = top; step >= 1; step >>= 1) {
+        const int idx = pos + step;
+        const int probe = idx <= n ? idx : n;  // keep the read in range; the result is discarded when idx > n
+        pos = (idx <= n && tab[probe - 1] < v) ? idx : pos;
+    }
+    return pos;
+}
+
+// K > 0: the K = k nearest OTHER points are kept in registers (sorted insertion: min/max only).  K == 0: any k,
+// selection by repeated minimum passes.  TI points are processed concurrently per lane.
+template <int K, int TI>
 __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __restrict__ members,
                                                         const double* __restrict__ prep_px,
                                                         const double* __restrict__ table_psi,
@@ -248,13 +289,15 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
                                                         float* __restrict__ out, size_t num_voxels, int cs, int k,
                                                         int estimator, int to_cc) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* s_px = reinterpret_cast<double*>(smem);
-    double* s_nq = s_px + cs;
-    double* s_psi = s_nq + cs;                                     // cs + 1 entries: psi(0..cs)
+    double* s_px = reinterpret_cast<double*>(smem);  // member order
+    double* s_spx = s_px + cs;                       // ascending
+    double* s_nq = s_spx + cs;
+    double* s_psi = s_nq + cs;                                                  // cs + 1 entries: psi(0..cs)
     float* s_y = reinterpret_cast<float*>(s_psi + (cs + 1) + ((cs + 1) & 1));  // keep 16-byte alignment
     const int lane = threadIdx.x;
     for (int i = lane; i < cs; i += 64) {
         s_px[i] = prep_px[i];
+        s_spx[i] = prep_px[cs + i];
         s_nq[i] = noise_query[i];
     }
     for (int i = lane; i <= cs; i += 64) s_psi[i] = table_psi[i];
@@ -269,52 +312,62 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
     }
     __syncthreads();
 
-    const int kk = k < cs - 1 ? k : cs - 1;  // (kk+1)-th smallest distance including the point itself
+    const int kk = k < cs - 1 ? k : cs - 1;  // neighbours besides the point itself (a kd-tree returns at most cs points)
+    int top = 1;
+    while (top * 2 <= cs) top *= 2;
     const double factor = 1.0 / double(cs);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     double sum_x = 0.0, sum_y = 0.0;
 
 #pragma unroll 1
-    for (int i0 = 0; i0 < cs; i0 += kTI) {
-        double pxi[kTI], pyi[kTI], rx[kTI], ry[kTI];
+    for (int i0 = 0; i0 < cs; i0 += TI) {
+        double pxi[TI], pyi[TI], rx[TI], ry[TI];
 #pragma unroll
-        for (int t = 0; t < kTI; t++) {
+        for (int t = 0; t < TI; t++) {
             const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
             pxi[t] = s_px[ii];
             pyi[t] = double(s_y[ii * 64 + lane]) + s_nq[ii];
         }
-        // ---- pass A: distance to the k-th neighbour (Chebyshev), MutualInformation.cpp:430-434
-        double dk[kTI];
-        if constexpr (KP1 > 0) {
-            double best[kTI][KP1];
+        const int i1 = (i0 + TI < cs) ? i0 + TI : cs;
+        // ---- pass A: Chebyshev distance to the k-th neighbour (the (k+1)-th smallest distance including the zero
+        //      distance to the point itself, MutualInformation.cpp:430-434)
+        double dk[TI];
+        if constexpr (K > 0) {
+            double best[TI][K];
 #pragma unroll
-            for (int t = 0; t < kTI; t++)
+            for (int t = 0; t < TI; t++)
 #pragma unroll
-                for (int q = 0; q < KP1; q++) best[t][q] = inf;
-#pragma unroll 2
-            for (int j = 0; j < cs; j++) {
+                for (int q = 0; q < K; q++) best[t][q] = inf;
+            auto visit = [&](int j, bool may_be_self) {
                 const double pxj = s_px[j];
                 const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
 #pragma unroll
-                for (int t = 0; t < kTI; t++) {
-                    double d = fmax(fabs(pxi[t] - pxj), fabs(pyi[t] - pyj));
+                for (int t = 0; t < TI; t++) {
+                    double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
+                    if (may_be_self) d = (j == i0 + t) ? inf : d;
 #pragma unroll
-                    for (int q = 0; q < KP1; q++) {
-                        const double lo = fmin(best[t][q], d);
-                        d = fmax(best[t][q], d);
+                    for (int q = 0; q < K; q++) {
+                        const double lo = min_f64(best[t][q], d);
+                        if (q + 1 < K) d = max_f64(best[t][q], d);
                         best[t][q] = lo;
                     }
                 }
-            }
+            };
+#pragma unroll 2
+            for (int j = 0; j < i0; j++) visit(j, false);
+#pragma unroll 1
+            for (int j = i0; j < i1; j++) visit(j, true);
+#pragma unroll 2
+            for (int j = i1; j < cs; j++) visit(j, false);
 #pragma unroll
-            for (int t = 0; t < kTI; t++) dk[t] = best[t][KP1 - 1];
+            for (int t = 0; t < TI; t++) dk[t] = best[t][K - 1];
         } else {
 #pragma unroll
-            for (int t = 0; t < kTI; t++) {
+            for (int t = 0; t < TI; t++) {
                 double cur = -1.0, m = 0.0;
                 int cnt = 0;
 #pragma unroll 1
-                for (int pass = 0; pass <= kk; pass++) {
+                for (int pass = 0; pass < kk; pass++) {
                     m = inf;
                     int c = 0;
 #pragma unroll 2
@@ -322,13 +375,13 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
                         const double pxj = s_px[j];
                         const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
                         const double d = fmax(fabs(pxi[t] - pxj), fabs(pyi[t] - pyj));
-                        if (d > cur) {
+                        if (d > cur && j != i0 + t) {
                             c = (d < m) ? 1 : (d == m ? c + 1 : c);
                             m = fmin(m, d);
                         }
                     }
                     cnt += c;
-                    if (cnt >= kk + 1) break;
+                    if (cnt >= kk) break;
                     cur = m;
                 }
                 dk[t] = m;
@@ -337,18 +390,18 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
         // ---- search radii
         if (estimator == 1) {
 #pragma unroll
-            for (int t = 0; t < kTI; t++) rx[t] = ry[t] = dk[t] - kCountSlack;  // includeCenter, :196-197
+            for (int t = 0; t < TI; t++) rx[t] = ry[t] = dk[t] - kCountSlack;  // includeCenter, :196-197
         } else {
-            // KSG-2: extents of the k+1 nearest points per dimension (:485-499), then +slack (:198-199)
-            double ex[kTI], ey[kTI];
+            // KSG-2: extents of the k+1 nearest points (incl. itself) per dimension (:485-499), then +slack (:198-199)
+            double ex[TI], ey[TI];
 #pragma unroll
-            for (int t = 0; t < kTI; t++) ex[t] = ey[t] = 0.0;
+            for (int t = 0; t < TI; t++) ex[t] = ey[t] = 0.0;
 #pragma unroll 2
             for (int j = 0; j < cs; j++) {
                 const double pxj = s_px[j];
                 const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
 #pragma unroll
-                for (int t = 0; t < kTI; t++) {
+                for (int t = 0; t < TI; t++) {
                     const double ax = fabs(pxi[t] - pxj), ay = fabs(pyi[t] - pyj);
                     const bool in = fmax(ax, ay) <= dk[t];
                     ex[t] = in ? fmax(ex[t], ax) : ex[t];
@@ -356,34 +409,31 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
                 }
             }
 #pragma unroll
-            for (int t = 0; t < kTI; t++) {
+            for (int t = 0; t < TI; t++) {
                 rx[t] = ex[t] + kCountSlack;
                 ry[t] = ey[t] + kCountSlack;
             }
         }
-        // ---- pass C: marginal counts  #{ j : c - r <= v_j < c + r }  (:201-233)
-        double lox[kTI], hix[kTI], loy[kTI], hiy[kTI];
-        int cx[kTI], cy[kTI];
+        // ---- pass C: marginal counts  #{ j : c - r <= v_j < c + r }  (:201-233).  x: two binary searches in the sorted
+        //      reference coordinates (like the reference); y: compares against every point.
+        double loy[TI], hiy[TI];
+        int cx[TI], cy[TI];
 #pragma unroll
-        for (int t = 0; t < kTI; t++) {
-            lox[t] = pxi[t] - rx[t];
-            hix[t] = pxi[t] + rx[t];
+        for (int t = 0; t < TI; t++) {
+            const double lox = pxi[t] - rx[t], hix = pxi[t] + rx[t];
+            cx[t] = count_less(s_spx, cs, top, hix) - count_less(s_spx, cs, top, lox);
             loy[t] = pyi[t] - ry[t];
             hiy[t] = pyi[t] + ry[t];
-            cx[t] = cy[t] = 0;
+            cy[t] = 0;
         }
 #pragma unroll 2
         for (int j = 0; j < cs; j++) {
-            const double pxj = s_px[j];
             const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
 #pragma unroll
-            for (int t = 0; t < kTI; t++) {
-                cx[t] += (pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
-                cy[t] += (pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
-            }
+            for (int t = 0; t < TI; t++) cy[t] += (pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
         }
 #pragma unroll
-        for (int t = 0; t < kTI; t++) {
+        for (int t = 0; t < TI; t++) {
             if (i0 + t < cs) {
                 int nx = cx[t] > 1 ? cx[t] : 1;
                 int ny = cy[t] > 1 ? cy[t] : 1;
@@ -466,20 +516,20 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     double* prep = reinterpret_cast<double*>(d_prep);
-    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(64), 0, s, ref, d_members, cs, noise_ref, prep);
+    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, noise_ref, prep);
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
-    const size_t lds = size_t(3 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
+    const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
     const int kk = a.k < cs - 1 ? a.k : cs - 1;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-#define CRF_LAUNCH_KRASKOV(KP1)                                                                                      \
-    hipLaunchKernelGGL((mi_kraskov_kernel<KP1>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
+#define CRF_LAUNCH_KRASKOV(K, TI)                                                                                     \
+    hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
                        d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
-    switch (kk + 1) {
-        case 2: CRF_LAUNCH_KRASKOV(2); break;
-        case 3: CRF_LAUNCH_KRASKOV(3); break;
-        case 4: CRF_LAUNCH_KRASKOV(4); break;
-        case 5: CRF_LAUNCH_KRASKOV(5); break;
-        default: CRF_LAUNCH_KRASKOV(0); break;
+    switch (kk) {
+        case 1: CRF_LAUNCH_KRASKOV(1, 8); break;
+        case 2: CRF_LAUNCH_KRASKOV(2, 8); break;
+        case 3: CRF_LAUNCH_KRASKOV(3, 8); break;
+        case 4: CRF_LAUNCH_KRASKOV(4, 4); break;
+        default: CRF_LAUNCH_KRASKOV(0, 1); break;
     }
 #undef CRF_LAUNCH_KRASKOV
     if (ev_end) (void)hipEventRecord(ev_end, s);

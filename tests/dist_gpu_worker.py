@@ -55,7 +55,9 @@ def main():
             else:
                 ok = np.allclose(got, want, rtol=1e-5, atol=1e-6, equal_nan=True)
             if not ok:
-                bad.append((rank, measure.name, (x, y, z)))
+                diff = np.flatnonzero(~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))))
+                bad.append((rank, measure.name, (x, y, z), int(diff.size), int(diff[0]), float(got[diff[0]]),
+                            float(want[diff[0]])))
     flag = torch.tensor([len(bad)])
     dist.all_reduce(flag)
     eng.close()

@@ -40,7 +40,7 @@ def test_rank_ties_everywhere(engine, oracle, measure, omeasure):
     """Heavily tied data (values rounded to a few levels): fractional ranks, tau-b tie terms, x-tie groups, the
     reference's ignored joint ties."""
     rng = np.random.default_rng(3)
-    for cs in (8, 24, 64, 100):
+    for cs in (8, 24, 64, 100, 128):   # > 64: split-sort kernels + deferred (tie) list handled by the monolithic pass
         ens = np.round(rng.standard_normal((cs, 4, 8, 16)) * 1.5).astype(np.float32)
         ens[:, 0, 0, 0] = 2.0                       # all-equal voxel: 0/0 -> NaN (Kendall), NaN (Spearman)
         ens[:, 0, 0, 1] = np.arange(cs)             # strictly increasing
