@@ -72,6 +72,9 @@ class ShardedCorrField:
         self._slot = 0
         self._pending = []  # [(ref_xyz, slot)] prefetched, not yet consumed
         self._cuda = self.device.type == "cuda"
+        self._stage_through_host = bool(self._cuda and world > 1 and dist.get_backend(group) == "gloo")
+        if self._stage_through_host:
+            self._host_ref = torch.empty(cs, dtype=torch.float32)
         if self._cuda:
             self._comm_stream = torch.cuda.Stream(device=self.device)
             self._ready = [torch.cuda.Event() for _ in range(self._nbuf)]   # vector landed in buffer[slot]
@@ -108,7 +111,17 @@ class ShardedCorrField:
         if self.rank == owner:
             self.engine.gather_reference_device(x, y, local_z, buf, stream_ptr)
         if self.world > 1:
-            self._dist.broadcast(buf, src=self._global_rank(owner), group=self.group)
+            if self._stage_through_host:
+                # rehearsal mode (gloo process group with GPU tensors, e.g. several ranks sharing one GPU): stage the
+                # cs floats through a host tensor explicitly instead of relying on gloo's own CUDA staging
+                if self.rank == owner:
+                    self._comm_stream.synchronize()
+                    self._host_ref.copy_(buf)
+                self._dist.broadcast(self._host_ref, src=self._global_rank(owner), group=self.group)
+                if self.rank != owner:
+                    buf.copy_(self._host_ref)
+            else:
+                self._dist.broadcast(buf, src=self._global_rank(owner), group=self.group)
 
     def prefetch(self, ref_xyz):
         """Starts gather + broadcast of the reference vector of a FUTURE compute(ref_xyz) on the communication stream.
