@@ -107,15 +107,21 @@ def main():
 
     pts = reference_points(xs, ys, zs, args.warmup + args.steps)
 
+    LOOKAHEAD = 8  # reference vectors exchanged per collective (N > 1)
+
     def run(lo, hi):
-        """Steps lo..hi-1.  N > 1: the exchange (owner gathers the reference vector on its device -> RCCL broadcast) of
-        step i+1 is started on the communication stream before the kernel of step i is enqueued, so it overlaps it."""
-        if world > 1:
-            sharded.prefetch(pts[lo])
-        for i in range(lo, hi):
-            if world > 1 and i + 1 < hi:
-                sharded.prefetch(pts[i + 1])
-            sharded.compute(measure, out, pts[i], **kwargs)
+        """Steps lo..hi-1.  N > 1: the reference vectors of the next LOOKAHEAD requested points are exchanged in ONE
+        collective (owners gather on their device -> RCCL all-reduce of LOOKAHEAD*cs floats) on the communication stream,
+        one batch ahead of the kernels that consume them, so the exchange overlaps the evaluation of earlier steps."""
+        if world == 1:
+            for i in range(lo, hi):
+                sharded.compute(measure, out, pts[i], **kwargs)
+            return
+        for b0 in range(lo, hi, LOOKAHEAD):
+            b1 = min(b0 + LOOKAHEAD, hi)
+            sharded.prefetch_batch(pts[b0:b1])
+            for i in range(b0, b1):
+                sharded.compute(measure, out, pts[i], **kwargs)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,10 +130,16 @@ def main():
             torch.cuda.synchronize()
 
     # untimed spin-up (clock ramp), then the W untimed warm-up steps, then exactly K timed steps
+    # (the number of spin-up rounds is decided by rank 0 and broadcast: every rank must issue the same collectives)
     t_spin = time.perf_counter()
-    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+    run(0, max(args.warmup, 1))
+    torch.cuda.synchronize()
+    t_round = max(time.perf_counter() - t_spin, 1e-4)
+    rounds = torch.tensor([int(args.spinup_ms * 1e-3 / t_round) if args.spinup_ms > 0 else 0], device="cuda")
+    if world > 1:
+        dist.broadcast(rounds, src=0)
+    for _ in range(int(rounds[0])):
         run(0, max(args.warmup, 1))
-        torch.cuda.synchronize()
     fence()
     run(0, args.warmup)
     fence()
@@ -175,7 +187,7 @@ def main():
             "config": {"workload": f"{args.measure} correlation field, {xs}x{ys}x{zs} grid x {cs} ensemble members "
                                    "(synthetic box ensemble), one moving reference point per step",
                        "grid": [xs, ys, zs], "members": cs, "measure": args.measure,
-                       "sharding": f"z-slab x{world}" + (", reference vector broadcast over RCCL" if world > 1 else ""),
+                       "sharding": f"z-slab x{world}" + (f", reference vectors exchanged over RCCL ({LOOKAHEAD} requested points per collective)" if world > 1 else ""),
                        "resident": "members and result in HBM"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }

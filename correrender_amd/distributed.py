@@ -71,6 +71,10 @@ class ShardedCorrField:
         self._ref = [torch.empty(cs, dtype=torch.float32, device=self.device) for _ in range(self._nbuf)]
         self._slot = 0
         self._pending = []  # [(ref_xyz, slot)] prefetched, not yet consumed
+        self._batch = [None, None]       # [R, cs] row buffers of prefetch_batch(), double-buffered
+        self._batch_flip = 0
+        self._batch_ready = [None, None]
+        self._batch_done = [None, None]
         self._cuda = self.device.type == "cuda"
         self._stage_through_host = bool(self._cuda and world > 1 and dist.get_backend(group) == "gloo")
         if self._stage_through_host:
@@ -78,6 +82,7 @@ class ShardedCorrField:
         if self._cuda:
             self._comm_stream = torch.cuda.Stream(device=self.device)
             self._ready = [torch.cuda.Event() for _ in range(self._nbuf)]   # vector landed in buffer[slot]
+            self._batch_ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._done = [None] * self._nbuf                                # last kernel that read buffer[slot]
         self._minmax = None
 
@@ -142,6 +147,50 @@ class ShardedCorrField:
             self._exchange(ref_xyz, buf, 0)
         self._pending.append((tuple(ref_xyz), slot))
 
+    def prefetch_batch(self, points):
+        """Exchanges the reference vectors of SEVERAL upcoming compute() calls in one collective: every rank gathers, on
+        its device, the vectors of the points whose slice it owns into the rows of a zeroed [R, cs] buffer, and one
+        all-reduce(SUM) of R*cs floats gives every rank every row (a sum of one value and zeros is that value; the only
+        bit pattern not preserved is -0.0, which no estimator distinguishes from +0.0).  One collective per R
+        evaluations instead of one per evaluation: at 8 GPUs a 256^3 x 64 evaluation is ~0.1 ms per rank, the same order
+        as the launch latency of a collective.  Rows are consumed, in order, by the next len(points) compute() calls."""
+        points = [tuple(p) for p in points]
+        if self._pending:
+            raise RuntimeError("prefetch_batch() needs all earlier prefetches to be consumed")
+        torch = self._torch
+        r = len(points)
+        b = self._batch_flip
+        self._batch_flip ^= 1
+        if self._batch[b] is None or self._batch[b].shape[0] < r:
+            self._batch[b] = torch.empty((max(r, 8), self.cs), dtype=torch.float32, device=self.device)
+        rows = self._batch[b]
+        owners = [slab_owner(self.zs, self.world, p[2]) for p in points]
+
+        def fill(stream_ptr):
+            rows[:r].zero_()
+            for i, ((x, y, _), (owner, local_z)) in enumerate(zip(points, owners)):
+                if owner == self.rank:
+                    self.engine.gather_reference_device(x, y, local_z, rows[i], stream_ptr)
+            if self.world > 1:
+                if self._stage_through_host:
+                    self._comm_stream.synchronize()
+                    host = rows[:r].cpu()
+                    self._dist.all_reduce(host, op=self._dist.ReduceOp.SUM, group=self.group)
+                    rows[:r].copy_(host)
+                else:
+                    self._dist.all_reduce(rows[:r], op=self._dist.ReduceOp.SUM, group=self.group)
+
+        if self._cuda:
+            with torch.cuda.stream(self._comm_stream):
+                if self._batch_done[b] is not None:
+                    self._comm_stream.wait_event(self._batch_done[b])  # last kernel that read this batch buffer
+                fill(self._comm_stream.cuda_stream)
+                self._batch_ready[b].record(self._comm_stream)
+        else:
+            fill(0)
+        for i, p in enumerate(points):
+            self._pending.append((p, ("batch", b, i, i == r - 1)))
+
     def compute(self, measure, out, ref_xyz, **kw):
         """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats), on the
         current torch stream, stream-ordered, without host synchronisation."""
@@ -158,14 +207,26 @@ class ShardedCorrField:
                 raise RuntimeError("compute() must consume prefetched reference points in order")
             self.prefetch(ref_xyz)
         _, slot = self._pending.pop(0)
-        buf = self._ref[slot]
         stream_ptr = 0
+        cur = None
         if self._cuda:
             cur = self._torch.cuda.current_stream(self.device)
-            cur.wait_event(self._ready[slot])
             stream_ptr = cur.cuda_stream
+        if isinstance(slot, tuple):  # a row of a batched exchange
+            _, b, row, last = slot
+            if cur is not None and row == 0:
+                cur.wait_event(self._batch_ready[b])
+            self.engine.compute_device(measure, out, device_reference=self._batch[b][row], stream=stream_ptr, **kw)
+            if cur is not None and last:
+                ev = self._torch.cuda.Event()
+                ev.record(cur)
+                self._batch_done[b] = ev
+            return out
+        buf = self._ref[slot]
+        if cur is not None:
+            cur.wait_event(self._ready[slot])
         self.engine.compute_device(measure, out, device_reference=buf, stream=stream_ptr, **kw)
-        if self._cuda:
+        if cur is not None:
             ev = self._torch.cuda.Event()
             ev.record(cur)
             self._done[slot] = ev

@@ -38,9 +38,13 @@ def main():
     for measure in (Measure.PEARSON, Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED,
                     Measure.MUTUAL_INFORMATION_KRASKOV):
         points = [(1, 2, 0), (12, 8, zs // 2), (23, 15, zs - 1), (5, 5, 1)]
-        sharded.prefetch(points[0])                      # pipelined exchange: step i+1's broadcast overlaps step i
+        batched = measure in (Measure.SPEARMAN, Measure.MUTUAL_INFORMATION_BINNED)
+        if batched:
+            sharded.prefetch_batch(points)               # one collective for all four reference vectors
+        else:
+            sharded.prefetch(points[0])                  # pipelined exchange: step i+1's broadcast overlaps step i
         for pi, (x, y, z) in enumerate(points):
-            if pi + 1 < len(points):
+            if not batched and pi + 1 < len(points):
                 sharded.prefetch(points[pi + 1])
             out = torch.empty(xs * ys * zl, dtype=torch.float32, device=dev)
             sharded.compute(measure, out, (x, y, z), k=2)

@@ -61,13 +61,17 @@ def _worker(rank, world, port, zs, result_file):
         points = [(3, 4, 0), (5, 5, zs // 2), (11, 9, zs - 1), (0, 0, zs // 2 - 1), (6, 2, zs // 2)]
         for measure in (Measure.PEARSON, Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED,
                         Measure.MUTUAL_INFORMATION_KRASKOV):
-            pipelined = measure in (Measure.PEARSON, Measure.KENDALL)   # exercise prefetch() as well as plain compute()
+            # exercise all three exchange forms: per-point prefetch(), batched prefetch_batch(), plain compute()
+            pipelined = measure in (Measure.PEARSON, Measure.KENDALL)
+            batched = measure in (Measure.SPEARMAN, Measure.MUTUAL_INFORMATION_KRASKOV)
             if pipelined:
                 sharded.prefetch(points[0])
             for pi, (x, y, z) in enumerate(points):
                 out = torch.empty(xs * ys * zl, dtype=torch.float32)
                 if pipelined and pi + 1 < len(points):
                     sharded.prefetch(points[pi + 1])
+                if batched and pi % 3 == 0:
+                    sharded.prefetch_batch(points[pi:pi + 3])
                 sharded.compute(measure, out, (x, y, z), k=2)
                 gathered = [torch.empty(xs * ys * slab_bounds(zs, world, r)[1], dtype=torch.float32)
                             for r in range(world)] if rank == 0 else None
