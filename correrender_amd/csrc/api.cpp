@@ -49,6 +49,8 @@ struct crf_context {
     float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
     double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
     uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
+    unsigned char* d_workspace = nullptr;  // voxel tiles of the generic (cs > 128) kernels, lazily
+    size_t workspace_bytes = 0;
     uint32_t* d_minmax = nullptr;
     bool minmax_valid = false;
     float min_v = 0.f, max_v = 0.f;
@@ -217,6 +219,7 @@ void crf_destroy(crf_context* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_todo) (void)hipFree(c->d_todo);
+    if (c->d_workspace) (void)hipFree(c->d_workspace);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     for (auto& p : c->ev_pending) {
         (void)hipEventDestroy(p.first);
@@ -241,7 +244,10 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_todo) (void)hipFree(c->d_todo);
+    if (c->d_workspace) (void)hipFree(c->d_workspace);
     c->d_todo = nullptr;
+    c->d_workspace = nullptr;
+    c->workspace_bytes = 0;
     c->d_tables = nullptr;
     c->d_member_table = nullptr;
     c->d_ref = nullptr;
@@ -371,6 +377,32 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     const int vpt = std::min(c->max_vpt, alignment_vpt(out));
     crf::LaunchInfo info;
     hipError_t e = hipSuccess;
+    if (p->measure != CRF_PEARSON && c->cs > crf::kMaxSortMembers) {
+        // any-member-count path (kernels_generic.hip)
+        if (c->cs > crf::kMaxGenericMembers)
+            return fail(c, CRF_ERR_UNSUPPORTED, fmt("measure %d supports at most %d members (got %d)", p->measure,
+                                                    crf::kMaxGenericMembers, c->cs));
+        if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
+            return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
+        if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || p->k > c->cs))
+            return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+        const size_t need = crf::generic_workspace_bytes(c->cs, c->num_voxels);
+        if (need > c->workspace_bytes) {
+            if (c->d_workspace) (void)hipFree(c->d_workspace);
+            c->d_workspace = nullptr;
+            c->workspace_bytes = 0;
+            CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_workspace), need));
+            c->workspace_bytes = need;
+        }
+        crf::GenericArgs ga{p->measure, p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query, p->k,
+                            p->kraskov_estimator_index == 2 ? 2 : 1};
+        e = crf::launch_generic(c->d_member_table, c->cs, c->num_voxels, ref, ga, c->d_tables, c->d_prep, c->d_workspace,
+                                out, s, e0, e1, &info);
+        c->last_kernel = info.kernel_name ? info.kernel_name : "";
+        if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+        if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+        return CRF_OK;
+    }
     switch (p->measure) {
         case CRF_PEARSON:
             e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, ref, c->d_prep, out, s, e0, e1,

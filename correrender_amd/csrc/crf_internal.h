@@ -14,6 +14,10 @@ constexpr int kMaxRegisterMembers = 256;
 constexpr int kMaxSortMembers = 128;
 // Prepared reference-derived table: floats (see each kernels_*.hip for its layout).
 constexpr size_t kPrepBytes = 64 * 1024;
+// Largest member count of the generic (any-cs) kernels: bounded by the preparation scratch (2*cs ints / doubles).
+constexpr int kMaxGenericMembers = 2048;
+// where binned_prep_kernel leaves the reference-side entropy sum (fp64) inside the preparation scratch
+constexpr size_t kBinnedSxOffset = kPrepBytes - 16;
 
 // Where a preparation kernel takes the reference vector from: an explicit device array of cs floats (SEPARATE mode,
 // or a vector received from another rank), or -- fused gather -- members[c][voxel]
@@ -75,5 +79,26 @@ struct KraskovArgs {
 hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+
+// ---- kernels_generic.hip: any member count (O(cs^2) counting algorithms, runtime loops) ------------------
+struct GenericArgs {
+    int measure;  // crf_measure value
+    int num_bins;
+    float min_ref, max_ref, min_query, max_query;
+    int k, estimator;
+};
+// workspace: generic_workspace_bytes(cs, num_voxels) bytes of device memory (per-block voxel tiles)
+size_t generic_workspace_bytes(int cs, size_t num_voxels);
+hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                          const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
+                          float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+// preparation launchers shared with the generic path (kernels_rank.hip / kernels_mi.hip); n_pad = table stride
+void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s);
+void launch_kendall_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, int* d_prep,
+                         hipStream_t s);
+void launch_binned_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, const BinnedArgs& a,
+                        const double* tableT, int* d_prep, hipStream_t s);
+void launch_kraskov_prep(const RefSource& ref, const float* const* d_members, int cs, const double* noise_ref,
+                         double* d_prep, hipStream_t s);
 
 }  // namespace crf

@@ -1,0 +1,352 @@
+// kernels_generic.hip -- Spearman / Kendall / binned MI / Kraskov MI for ANY member count (cs up to kMaxGenericMembers).
+//
+// The register-resident kernels (kernels_rank.hip, kernels_mi.hip) are instantiated for cs <= 128; the reference has
+// no such limit (its own synthetic data set has 1000 members, scripts/generate_synth_box_ensembles.py:47).  These
+// kernels keep the same mapping -- one lane = one voxel -- but hold the voxel's cs values in a per-lane column
+// [member][lane] of a tile that lives in LDS when it fits and otherwise in a global workspace slice owned by the block
+// (persistent blocks, grid-stride over 64-voxel tiles), and use O(cs^2) counting formulations with runtime loops:
+//   Spearman  2*rank_e = 1 + sum_j (2 [v_j < v_e] + [v_j == v_e])           (mid-ranks, Correlation.cpp:277-303)
+//   Kendall   S_y = #{ a < b in x order, not in the same x-tie group : y_a > y_b },  n2 = #{ a < b : y_a == y_b }
+//   binned    first-occurrence scan over the voxel's cell codes (the skipped-sample path of mi_binned_kernel)
+//   Kraskov   the same brute-force k-select as mi_kraskov_kernel, tile pointer instead of LDS
+// Integer cores are exact; fp32 tails use the reference's operation order; fp64 sums of the MI estimators differ from
+// the reference's order at the 1e-16 level (see kernels_mi.hip).  Throughput is secondary here: at cs = 1000 the
+// pair loops are ~10^6 compares per voxel, ~20 ms for the reference's 128x128x32 data set.
+#include <cstdlib>
+
+#include "crf_device.h"
+#include "crf_internal.h"
+
+namespace crf {
+
+namespace {
+constexpr int kGenericBlocks = 1024;        // persistent blocks (4 per CU)
+constexpr size_t kLdsTileLimit = 60 * 1024;  // use LDS for the tile when it fits under the default 64 KB limit
+
+__host__ __device__ inline size_t tile_bytes(int cs) { return size_t(cs) * 64 * (sizeof(float) + sizeof(uint16_t)); }
+}  // namespace
+
+size_t generic_workspace_bytes(int cs, size_t num_voxels) {
+    if (tile_bytes(cs) <= kLdsTileLimit) return 0;
+    const size_t tiles = (num_voxels + 63) / 64;
+    return tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+}
+
+__device__ __forceinline__ float mi_to_cc_generic(float mi);  // defined below (same map as kernels_mi.hip)
+
+// ---- per-voxel evaluators: `vals` / `aux` point at this lane's column (stride 64 elements) ------------------
+
+// Spearman: ranks by counting, then computePearson2<float>(referenceRanks, ranks, cs) in member order.
+__device__ float spearman_voxel(const float* vals, uint16_t* aux, const float* __restrict__ prep_a, int cs) {
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) {
+        const float ve = vals[e * 64];
+        uint32_t s = 0;
+#pragma unroll 4
+        for (int j = 0; j < cs; j++) {
+            const float vj = vals[j * 64];
+            s += (vj < ve) ? 2u : ((vj == ve) ? 1u : 0u);
+        }
+        aux[e * 64] = uint16_t(s + 1u);  // 2 * rank (self contributes the +1 of [v_e == v_e])
+    }
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanY = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) meanY += invN * (0.5f * float(aux[e * 64]));
+    float varY = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) {
+        const float d = 0.5f * float(aux[e * 64]) - meanY;
+        varY += invNm1 * d * d;
+    }
+    const float sdY = sqrtf(varY);
+    float r = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) r += prep_a[e] * ((0.5f * float(aux[e * 64]) - meanY) / sdY);
+    return r;
+}
+
+// Kendall tau-b; vals hold the voxel's values in reference-sorted order (slot = position in the x order).
+__device__ float kendall_voxel(const float* vals, const int* __restrict__ prep, int cs) {
+    const int* gend = prep + cs;  // slot -> last slot of its x-tie group
+    int32_t discordant = 0, n2 = 0;
+#pragma unroll 1
+    for (int i = 0; i < cs; i++) {
+        const float yi = vals[i * 64];
+        const int g = gend[i];
+#pragma unroll 1
+        for (int j = i + 1; j <= g; j++) n2 += (vals[j * 64] == yi) ? 1 : 0;  // same x: ties in y only
+#pragma unroll 4
+        for (int j = g + 1; j < cs; j++) {
+            const float yj = vals[j * 64];
+            n2 += (yj == yi) ? 1 : 0;
+            discordant += (yi > yj) ? 1 : 0;
+        }
+    }
+    const int32_t n = cs;
+    const int32_t n0 = (n * (n - 1)) / 2;
+    const int32_t n1 = prep[2 * cs];
+    const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
+    const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2));
+    return float(numerator) / denominator;
+}
+
+// Binned MI from the voxel's cell codes (b1 << 8 | b0, 0xFFFF = skipped sample) in aux.
+__device__ float binned_voxel(const uint16_t* aux, int total, bool table_ok, const double* __restrict__ tableT, int cs) {
+    double mi = 0.0;
+    if (total > 0) {
+        const double tot = double(total);
+        const double eps1 = 0.5 / double(cs);
+        const double eps2 = 0.5 / double(cs * cs);
+#pragma unroll 1
+        for (int i = 0; i < cs; i++) {
+            const uint32_t ci = aux[i * 64];
+            if (ci == 0xFFFFu) continue;
+            int cx = 0, cy = 0, cxy = 0;
+            bool fx = true, fy = true, fxy = true;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const uint32_t cj = aux[j * 64];
+                const bool ok = cj != 0xFFFFu;
+                const bool ex = ok && (cj & 0xFFu) == (ci & 0xFFu);
+                const bool ey = ok && (cj >> 8) == (ci >> 8);
+                cx += ex;
+                cy += ey;
+                cxy += (ex && ey);
+                if (j < i) {
+                    fx = fx && !ex;
+                    fy = fy && !ey;
+                    fxy = fxy && !(ex && ey);
+                }
+            }
+            if (table_ok) {  // every sample valid: p = c/cs, p ln p from the host-built table
+                if (fx) mi -= tableT[cx];
+                if (fy) mi -= tableT[cy];
+                if (fxy) mi += tableT[cxy];
+            } else {
+                if (fx) {
+                    const double p = double(cx) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fy) {
+                    const double p = double(cy) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fxy) {
+                    const double p = double(cxy) / tot;
+                    if (p > eps2) mi += p * log(p);
+                }
+            }
+        }
+    }
+    return float(mi);
+}
+
+__device__ __forceinline__ int count_less_generic(const double* tab, int n, int top, double v) {
+    int pos = 0;
+    for (int step = top; step >= 1; step >>= 1) {
+        const int idx = pos + step;
+        const int probe = idx <= n ? idx : n;
+        pos = (idx <= n && tab[probe - 1] < v) ? idx : pos;
+    }
+    return pos;
+}
+
+// Kraskov KSG-1 / KSG-2, any k: selection of the k-th neighbour distance by repeated minimum passes.
+__device__ float kraskov_voxel(const float* vals, const double* __restrict__ px, const double* __restrict__ spx,
+                               const double* __restrict__ nq, const double* __restrict__ psi, int cs, int k,
+                               int estimator) {
+    const int kk = k < cs - 1 ? k : cs - 1;
+    int top = 1;
+    while (top * 2 <= cs) top *= 2;
+    const double factor = 1.0 / double(cs);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const double slack = 1e-15;
+    double sum_x = 0.0, sum_y = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < cs; i++) {
+        const double pxi = px[i];
+        const double pyi = double(vals[i * 64]) + nq[i];
+        double cur = -1.0, m = 0.0;
+        int cnt = 0;
+#pragma unroll 1
+        for (int pass = 0; pass < kk; pass++) {
+            m = inf;
+            int c = 0;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const double d = fmax(fabs(pxi - px[j]), fabs(pyi - (double(vals[j * 64]) + nq[j])));
+                if (d > cur && j != i) {
+                    c = (d < m) ? 1 : (d == m ? c + 1 : c);
+                    m = fmin(m, d);
+                }
+            }
+            cnt += c;
+            if (cnt >= kk) break;
+            cur = m;
+        }
+        double rx, ry;
+        if (estimator == 1) {
+            rx = ry = m - slack;
+        } else {
+            double ex = 0.0, ey = 0.0;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const double ax = fabs(pxi - px[j]), ay = fabs(pyi - (double(vals[j * 64]) + nq[j]));
+                const bool in = fmax(ax, ay) <= m;
+                ex = in ? fmax(ex, ax) : ex;
+                ey = in ? fmax(ey, ay) : ey;
+            }
+            rx = ex + slack;
+            ry = ey + slack;
+        }
+        int cx = count_less_generic(spx, cs, top, pxi + rx) - count_less_generic(spx, cs, top, pxi - rx);
+        const double loy = pyi - ry, hiy = pyi + ry;
+        int cy = 0;
+#pragma unroll 4
+        for (int j = 0; j < cs; j++) {
+            const double pyj = double(vals[j * 64]) + nq[j];
+            cy += (pyj >= loy && pyj < hiy) ? 1 : 0;
+        }
+        cx = cx > 1 ? cx : 1;
+        cy = cy > 1 ? cy : 1;
+        if (estimator != 1) {
+            cx -= 1;
+            cy -= 1;
+        }
+        sum_x += factor * psi[cx];
+        sum_y += factor * psi[cy];
+    }
+    double c = psi[k <= cs ? k : cs];
+    if (estimator != 1) c -= 1.0 / double(k);
+    const double mi = -sum_x - sum_y + c + psi[cs];
+    const float res = float(mi);
+    return (res < 0.0f) ? 0.0f : res;
+}
+
+__global__ __launch_bounds__(64) void generic_kernel(const float* const* __restrict__ members,
+                                                     const void* __restrict__ prep, const double* __restrict__ tables,
+                                                     float* __restrict__ out, size_t num_voxels, int cs, GenericArgs a,
+                                                     unsigned char* __restrict__ workspace) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* tile = workspace ? workspace + size_t(blockIdx.x) * tile_bytes(cs) : smem;
+    const int lane = threadIdx.x;
+    float* vals = reinterpret_cast<float*>(tile) + lane;                                        // [cs][64]
+    uint16_t* aux = reinterpret_cast<uint16_t*>(tile + size_t(cs) * 64 * sizeof(float)) + lane;  // [cs][64]
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const int* prep_i = static_cast<const int*>(prep);
+    const size_t tiles = (num_voxels + 63) / 64;
+    const bool binned = a.measure == 3 || a.measure == 5;
+    const bool kendall = a.measure == 2;
+#pragma unroll 1
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t v = t * 64 + lane;
+        const uint32_t byte_offset = uint32_t(v) * 4u;  // lanes past the end read 0
+        bool is_nan = false;
+        int total = 0;
+        const float range_q = a.max_query - a.min_query;
+#pragma unroll 4
+        for (int e = 0; e < cs; e++) {
+            const float y = load_member_nt(members[kendall ? prep_i[e] : e], bytes, byte_offset);
+            is_nan |= (y != y);
+            vals[e * 64] = y;
+            if (binned) {  // cell code, as in mi_binned_kernel
+                const float q01 = (y - a.min_query) / range_q;
+                const int b0 = prep_i[e];
+                const bool valid = (q01 == q01) && b0 != 0xFFFF;
+                int b1 = int(double(q01) * double(a.num_bins));
+                b1 = b1 < 0 ? 0 : (b1 > a.num_bins - 1 ? a.num_bins - 1 : b1);
+                aux[e * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
+                total += valid ? 1 : 0;
+            }
+        }
+        float res;
+        switch (a.measure) {
+            case 1: res = spearman_voxel(vals, aux, static_cast<const float*>(prep), cs); break;
+            case 2: res = kendall_voxel(vals, prep_i, cs); break;
+            case 3:
+            case 5: {
+                const bool table_ok = total == cs && prep_i[cs] != 0;
+                res = binned_voxel(aux, total, table_ok, tables + (cs + 1), cs);
+                if (a.measure == 5) res = mi_to_cc_generic(res);
+                break;
+            }
+            default: {
+                const double* prep_d = static_cast<const double*>(prep);
+                res = kraskov_voxel(vals, prep_d, prep_d + cs, tables + 3 * cs + 2, tables, cs, a.k, a.estimator);
+                if (a.measure == 6) res = mi_to_cc_generic(res);
+                break;
+            }
+        }
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (v < num_voxels) out[v] = res;
+    }
+}
+
+// glibc-compatible expf for the MI-CC map: see kernels_mi.hip (same algorithm and table).
+__device__ const uint64_t kExp2Tab32G[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float mi_to_cc_generic(float mi) {
+    const float x = -2.0f * mi;
+    float e;
+    if (!(x > -80.0f && x < 80.0f)) {
+        e = expf(x);
+    } else {
+        const double shift = 0x1.8p+52;
+        double z = (0x1.71547652b82fep+0 * 32.0) * double(x);
+        double kd = z + shift;
+        const uint64_t ki = uint64_t(__double_as_longlong(kd));
+        kd -= shift;
+        const double r = z - kd;
+        const double s = __longlong_as_double((long long)(kExp2Tab32G[ki & 31u] + (ki << 47)));
+        z = (0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0) * r + (0x1.ebfce50fac4f3p-3 / 32.0 / 32.0);
+        const double r2 = r * r;
+        double y = (0x1.62e42ff0c52d6p-1 / 32.0) * r + 1.0;
+        y = z * r2 + y;
+        e = float(y * s);
+    }
+    return sqrtf(1.0f - e);
+}
+
+hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                          const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
+                          float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    switch (a.measure) {
+        case 1: launch_spearman_prep(ref, d_members, cs, d_prep, s); break;
+        case 2: launch_kendall_prep(ref, d_members, cs, cs, reinterpret_cast<int*>(d_prep), s); break;
+        case 3:
+        case 5: {
+            const BinnedArgs b{a.num_bins, a.min_ref, a.max_ref, a.min_query, a.max_query, a.measure == 5};
+            launch_binned_prep(ref, d_members, cs, cs, b, d_tables + (cs + 1), reinterpret_cast<int*>(d_prep), s);
+            break;
+        }
+        case 4:
+        case 6:
+            launch_kraskov_prep(ref, d_members, cs, d_tables + 2 * (cs + 1), reinterpret_cast<double*>(d_prep), s);
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    const size_t tiles = (num_voxels + 63) / 64;
+    const unsigned blocks = unsigned(tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+    const bool use_lds = tile_bytes(cs) <= kLdsTileLimit;
+    if (!use_lds && !d_workspace) return hipErrorInvalidValue;
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    hipLaunchKernelGGL(generic_kernel, dim3(blocks), dim3(64), use_lds ? tile_bytes(cs) : 0, s, d_members,
+                       static_cast<const void*>(d_prep), d_tables, d_out, num_voxels, cs, a,
+                       use_lds ? nullptr : d_workspace);
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "generic_kernel";
+    return hipGetLastError();
+}
+
+}  // namespace crf

@@ -75,12 +75,12 @@ __device__ __forceinline__ float mi_to_cc(float mi) {  // CorrelationCalculator.
 // ---------------------------------------------------------------------------------------------------------
 // Binned MI: reference-side preparation.
 //   prep (int32 view): [0, N) b0_e (kInvalidBin when the normalised reference value is NaN), [N] = 1 if every reference
-//   sample is valid; prep (fp64 view) at byte offset 4096: SX = sum over occupied reference bins of p ln p.
+//   sample is valid; prep (fp64 view) at byte offset kBinnedSxOffset: SX = sum over occupied reference bins of p ln p.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                          int cs, int n_pad, int nb, float min_ref, float max_ref,
                                                          const double* __restrict__ tableT, int* __restrict__ prep) {
-    __shared__ int b0s[kMaxSortMembers];
+    extern __shared__ int b0s[];  // cs ints
     __shared__ int all_valid;
     if (threadIdx.x == 0) all_valid = 1;
     __syncthreads();
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const fl
             sx += tableT[c];  // tableT[0] == 0
         }
         prep[n_pad] = all_valid;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(prep) + 4096) = sx;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(prep) + kBinnedSxOffset) = sx;
     }
 }
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
     const bool ref_all_valid = prep[N] != 0;
-    const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + 4096);
+    const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + kBinnedSxOffset);
 
     uint32_t a[N];
     bool is_nan = false;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
 __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                            int cs, const double* __restrict__ noise_ref,
                                                            double* __restrict__ prep) {
-    __shared__ double px[256];
+    extern __shared__ double px[];  // cs doubles
     for (int e = threadIdx.x; e < cs; e += blockDim.x) px[e] = double(load_ref(src, members, e)) + noise_ref[e];
     __syncthreads();
     for (int e = threadIdx.x; e < cs; e += blockDim.x) {
@@ -475,6 +475,18 @@ int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 12
 
 }  // namespace
 
+void launch_binned_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, const BinnedArgs& a,
+                        const double* tableT, int* d_prep, hipStream_t s) {
+    hipLaunchKernelGGL(binned_prep_kernel, dim3(1), dim3(64), size_t(cs) * sizeof(int), s, ref, d_members, cs, n_pad,
+                       a.num_bins, a.min_ref, a.max_ref, tableT, d_prep);
+}
+
+void launch_kraskov_prep(const RefSource& ref, const float* const* d_members, int cs, const double* noise_ref,
+                         double* d_prep, hipStream_t s) {
+    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(double), s, ref, d_members, cs,
+                       noise_ref, d_prep);
+}
+
 hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                             const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
@@ -488,8 +500,7 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     const int n_pad = pad_pow2(cs);
     int* prep = reinterpret_cast<int*>(d_prep);
     const double* tableT = d_tables + (cs + 1);
-    hipLaunchKernelGGL(binned_prep_kernel, dim3(1), dim3(64), 0, s, ref, d_members, cs, n_pad, a.num_bins, a.min_ref, a.max_ref,
-                       tableT, prep);
+    launch_binned_prep(ref, d_members, cs, n_pad, a, tableT, prep, s);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_binned_n<16, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
@@ -516,7 +527,7 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     double* prep = reinterpret_cast<double*>(d_prep);
-    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, noise_ref, prep);
+    launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
     const int kk = a.k < cs - 1 ? a.k : cs - 1;

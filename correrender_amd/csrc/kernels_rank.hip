@@ -44,8 +44,9 @@ __device__ __forceinline__ bool keys_hold_nan(uint32_t smallest_key, uint32_t la
 // Spearman: prep[e] = a_e = invNm1 * ((rx_e - mean) / sd) over the reference RANKS rx (CorrelationCalculator.cpp:859-865).
 __global__ __launch_bounds__(256) void spearman_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                             int cs, float* __restrict__ prep) {
-    __shared__ float ref[kMaxSortMembers];
-    __shared__ float rx[kMaxSortMembers];
+    extern __shared__ float prep_lds[];  // 2 * cs floats
+    float* ref = prep_lds;
+    float* rx = prep_lds + cs;
     __shared__ float sh[2];
     for (int i = threadIdx.x; i < cs; i += blockDim.x) ref[i] = load_ref(src, members, i);
     __syncthreads();
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256) void spearman_prep_kernel(RefSource src, const
 // [2N] n1 = sum over x-tie groups t(t-1)/2 (computeTiesB, Correlation.cpp:305-329), [2N+1] 1 if x has ties.
 __global__ __launch_bounds__(256) void kendall_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                            int cs, int n_pad, int* __restrict__ prep) {
-    __shared__ float ref[kMaxSortMembers];
+    extern __shared__ float prep_lds[];  // cs floats
+    float* ref = prep_lds;
     __shared__ int n1;
     if (threadIdx.x == 0) n1 = 0;
     for (int i = threadIdx.x; i < cs; i += blockDim.x) ref[i] = load_ref(src, members, i);
@@ -557,6 +559,17 @@ int env_waves(int fallback) {
 
 }  // namespace
 
+void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s) {
+    hipLaunchKernelGGL(spearman_prep_kernel, dim3(1), dim3(256), size_t(2 * cs) * sizeof(float), s, ref, d_members, cs,
+                       d_prep);
+}
+
+void launch_kendall_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, int* d_prep,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(kendall_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(float), s, ref, d_members, cs, n_pad,
+                       d_prep);
+}
+
 hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
                            uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                            LaunchInfo* info) {
@@ -568,7 +581,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    hipLaunchKernelGGL(spearman_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, d_prep);
+    launch_spearman_prep(ref, d_members, cs, d_prep, s);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -617,7 +630,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     }
     const int n_pad = pad_pow2(cs);
     int* prep = reinterpret_cast<int*>(d_prep);
-    hipLaunchKernelGGL(kendall_prep_kernel, dim3(1), dim3(256), 0, s, ref, d_members, cs, n_pad, prep);
+    launch_kendall_prep(ref, d_members, cs, n_pad, prep, s);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
