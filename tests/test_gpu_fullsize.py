@@ -1,0 +1,83 @@
+"""GPU, BASELINE.json's full single-GPU size (256^3 grid x 64 members, 4.3 GB generated on the device): parity through
+size-independent properties plus sampled comparison with the oracle.
+  * sampled voxels (random + the reference voxel + box plateaus): bit-exact vs the oracle for Pearson/Spearman/Kendall,
+    tolerance for the MI estimators -- the sampled member columns are gathered on the device and copied to the host;
+  * slab consistency: evaluating a z-slab as its own grid gives bit-for-bit the corresponding part of the whole result
+    (what the multi-GPU path relies on);
+  * reference voxel: every measure returns what the oracle returns for a vector against itself."""
+import numpy as np
+import pytest
+import torch
+
+from correrender_amd import Measure
+from parity import assert_bit_exact, assert_close
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+XS = YS = ZS = 256
+CS = 64
+SEED = 20260130
+
+
+@pytest.fixture(scope="module")
+def volume(engine):
+    members = torch.empty((CS, ZS, YS, XS), dtype=torch.float32, device="cuda")
+    for c in range(CS):
+        engine.synth_box_member(members[c], XS, YS, ZS, 0, ZS, c, CS, SEED)
+    torch.cuda.synchronize()
+    yield members
+    del members
+    torch.cuda.empty_cache()
+
+
+def _sample_indices():
+    rng = np.random.default_rng(5)
+    idx = rng.choice(XS * YS * ZS, size=60000, replace=False)
+    ref = (ZS // 2 * YS + YS // 8) * XS + XS // 8                      # the reference voxel (inside the first big box)
+    plateau = [((ZS // 2 + dz) * YS + YS // 8 + dy) * XS + XS // 8 + dx for dz in (-2, 0, 3) for dy in (-3, 1) for dx in (2, 5)]
+    return np.unique(np.concatenate([idx, [ref], plateau])).astype(np.int64)
+
+
+def test_full_size_sampled_parity_and_properties(engine, oracle, volume):
+    engine.set_grid(XS, YS, ZS, CS)
+    engine.bind_members(volume)
+    ref_xyz = (XS // 8, YS // 8, ZS // 2)
+    ref_values = engine.gather_reference(*ref_xyz)
+    idx = _sample_indices()
+    flat = volume.view(CS, -1)
+    cols = flat[:, torch.from_numpy(idx).cuda()].cpu().numpy()                  # [cs, n_samples] member columns
+    cols = np.ascontiguousarray(cols).reshape(CS, 1, 1, -1)
+    np.testing.assert_array_equal(cols[:, 0, 0, np.searchsorted(idx, (ref_xyz[2] * YS + ref_xyz[1]) * XS + ref_xyz[0])],
+                                  ref_values)
+    out = torch.empty(XS * YS * ZS, dtype=torch.float32, device="cuda")
+    results = {}
+    for m, om, exact in ((Measure.PEARSON, oracle_lib.PEARSON, True), (Measure.SPEARMAN, oracle_lib.SPEARMAN, True),
+                         (Measure.KENDALL, oracle_lib.KENDALL, True),
+                         (Measure.MUTUAL_INFORMATION_BINNED, oracle_lib.MI_BINNED, False)):
+        kw = {}
+        okw = {}
+        if not exact:
+            mm = engine.member_minmax()
+            kw = dict(num_bins=80, minmax_ref=mm, minmax_query=mm)
+            okw = dict(num_bins=80, minmax_ref=mm)
+        engine.compute_device(m, out, ref_xyz, **kw)
+        torch.cuda.synchronize()
+        got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+        want = oracle.field(om, cols, ref_values, **okw)
+        (assert_bit_exact if exact else assert_close)(got, want, f"{m.name} 256^3x64 sampled")
+        results[m] = out.clone()
+    # slab consistency (Pearson and Kendall): slices [96, 128) evaluated as their own grid
+    z0, zl = 96, 32
+    engine.set_grid(XS, YS, zl, CS)
+    engine.bind_members(volume[:, z0:z0 + zl])                                    # contiguous per member
+    slab_out = torch.empty(XS * YS * zl, dtype=torch.float32, device="cuda")
+    dref = torch.from_numpy(ref_values).cuda()
+    for m in (Measure.PEARSON, Measure.KENDALL):
+        engine.compute_device(m, slab_out, device_reference=dref)
+        torch.cuda.synchronize()
+        whole = results[m].view(ZS, YS * XS)[z0:z0 + zl].reshape(-1)
+        assert torch.equal(slab_out.view(torch.int32), whole.view(torch.int32)), f"{m.name}: slab != whole"
+    # the result has the expected structure: perfectly correlated plateau of the box that holds the reference point
+    p = results[Measure.PEARSON].view(ZS, YS, XS)
+    assert float(p[ZS // 2, YS // 8 + 2, XS // 8 + 3]) == pytest.approx(1.0, abs=1e-6)
+    assert abs(float(p[ZS // 2, YS // 2, XS // 2])) < 0.6                        # an uncorrelated voxel
