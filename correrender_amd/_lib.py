@@ -29,8 +29,16 @@ class CrfParams(C.Structure):
         ("min_ref", C.c_float), ("max_ref", C.c_float),
         ("min_query", C.c_float), ("max_query", C.c_float),
         ("reference_values", C.POINTER(C.c_float)),
-        ("reserved", C.c_int32 * 4),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
+
+
+class CrfRequest(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("xi", "yi", "zi", "i", "xj", "yj", "zj", "j")]
+
+
+FLAG_ABSOLUTE_VALUE = 1
 
 
 # every symbol include/corrfield.h declares: name -> (restype, argtypes)
@@ -48,6 +56,8 @@ SYMBOLS = {
     "crf_gather_reference_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
     "crf_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
     "crf_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, _VOIDP, _VOIDP]),
+    "crf_compute_requests": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_size_t, C.POINTER(C.c_float)]),
+    "crf_compute_requests_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_size_t, _VOIDP, _VOIDP]),
     "crf_set_profiling": (C.c_int, [_VOIDP, C.c_int]),
     "crf_take_kernel_time": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "crf_last_kernel_name": (C.c_char_p, [_VOIDP]),

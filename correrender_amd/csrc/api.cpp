@@ -51,6 +51,9 @@ struct crf_context {
     uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
     unsigned char* d_workspace = nullptr;  // voxel tiles of the generic (cs > 128) kernels, lazily
     size_t workspace_bytes = 0;
+    uint32_t* d_requests = nullptr;  // staging of host pair requests / their results, lazily
+    float* d_request_out = nullptr;
+    size_t request_capacity = 0;
     uint32_t* d_minmax = nullptr;
     bool minmax_valid = false;
     float min_v = 0.f, max_v = 0.f;
@@ -163,7 +166,7 @@ hipEvent_t take_event(crf_context* c) {
 
 extern "C" {
 
-int crf_abi_version(void) { return 1; }
+int crf_abi_version(void) { return 2; }
 
 const char* crf_last_error(const crf_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -220,6 +223,8 @@ void crf_destroy(crf_context* c) {
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_todo) (void)hipFree(c->d_todo);
     if (c->d_workspace) (void)hipFree(c->d_workspace);
+    if (c->d_requests) (void)hipFree(c->d_requests);
+    if (c->d_request_out) (void)hipFree(c->d_request_out);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     for (auto& p : c->ev_pending) {
         (void)hipEventDestroy(p.first);
@@ -464,6 +469,69 @@ int crf_compute(crf_context* c, const crf_params* p, float* host_out) {
     if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
     if (int r = crf_compute_device(c, p, nullptr, c->d_out, nullptr)) return r;
     CRF_HIP(c, hipMemcpyAsync(host_out, c->d_out, c->num_voxels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
+int crf_compute_requests_device(crf_context* c, const crf_params* p, const void* device_requests, size_t num_requests,
+                                void* device_out, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!p || (num_requests && (!device_requests || !device_out))) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (p->measure < CRF_PEARSON || p->measure > CRF_KMI_CC)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("unknown measure %d", p->measure));
+    for (int v : p->reserved)
+        if (v != 0) return fail(c, CRF_ERR_ARGUMENT, "crf_params.reserved must be zero");
+    if (c->cs > crf::kMaxGenericMembers)
+        return fail(c, CRF_ERR_UNSUPPORTED, fmt("pair requests support at most %d members", crf::kMaxGenericMembers));
+    if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
+    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || (p->k > c->cs && c->cs > 1)))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const size_t need = crf::pair_workspace_bytes(c->cs, num_requests);
+    if (need > c->workspace_bytes) {
+        if (c->d_workspace) (void)hipFree(c->d_workspace);
+        c->d_workspace = nullptr;
+        c->workspace_bytes = 0;
+        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_workspace), need));
+        c->workspace_bytes = need;
+    }
+    hipError_t e = crf::launch_pair_requests(c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                             static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
+                                             p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) != 0, c->d_tables,
+                                             c->d_workspace, static_cast<float*>(device_out), s);
+    c->last_kernel = "pair_request_kernel";
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
+int crf_compute_requests(crf_context* c, const crf_params* p, const crf_request* host_requests, size_t num_requests,
+                         float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (num_requests == 0) return CRF_OK;
+    if (!host_requests || !host_out) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    for (size_t r = 0; r < num_requests; r++) {
+        const crf_request& q = host_requests[r];
+        if (q.xi >= uint32_t(c->xs) || q.yi >= uint32_t(c->ys) || q.zi >= uint32_t(c->zs) || q.xj >= uint32_t(c->xs) ||
+            q.yj >= uint32_t(c->ys) || q.zj >= uint32_t(c->zs))
+            return fail(c, CRF_ERR_ARGUMENT, fmt("request %zu addresses a voxel outside the grid", r));
+    }
+    if (int r = bind_device(c)) return r;
+    if (num_requests > c->request_capacity) {
+        if (c->d_requests) (void)hipFree(c->d_requests);
+        if (c->d_request_out) (void)hipFree(c->d_request_out);
+        c->d_requests = nullptr;
+        c->d_request_out = nullptr;
+        c->request_capacity = 0;
+        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_requests), num_requests * sizeof(crf_request)));
+        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_request_out), num_requests * sizeof(float)));
+        c->request_capacity = num_requests;
+    }
+    CRF_HIP(c, hipMemcpyAsync(c->d_requests, host_requests, num_requests * sizeof(crf_request), hipMemcpyHostToDevice,
+                              c->stream));
+    if (int r = crf_compute_requests_device(c, p, c->d_requests, num_requests, c->d_request_out, nullptr)) return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_request_out, num_requests * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     return CRF_OK;
 }

@@ -26,6 +26,12 @@ __device__ __forceinline__ float buffer_load_f32_nt(RSRC rsrc, uint32_t byte_off
 __device__ __forceinline__ float load_member_nt(const float* base, uint32_t bytes, uint32_t byte_offset) {
     return buffer_load_f32_nt(make_member_rsrc(base, bytes), byte_offset);
 }
+// plain (cacheable) gather of one value: pair requests re-use voxels, so the default cache policy is kept
+__device__ __forceinline__ float load_member(const float* base, uint32_t byte_offset) {
+    typedef const float __attribute__((address_space(1)))* gptr;
+    typedef const char __attribute__((address_space(1)))* gcptr;
+    return *(gptr)((gcptr)base + byte_offset);
+}
 
 __device__ __forceinline__ float load_ref(const RefSource& r, const float* const* __restrict__ members, int c) {
     return r.values ? r.values[c] : members[c][r.voxel];

@@ -92,6 +92,12 @@ size_t generic_workspace_bytes(int cs, size_t num_voxels);
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+// pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}
+size_t pair_workspace_bytes(int cs, size_t num_requests);
+hipError_t launch_pair_requests(const float* const* d_members, int cs, int xs, int ys, size_t num_voxels,
+                                const uint32_t* d_requests, size_t num_requests, int measure, int num_bins, int k,
+                                bool use_abs, const double* d_tables, unsigned char* d_workspace, float* d_out,
+                                hipStream_t s);
 // preparation launchers shared with the generic path (kernels_rank.hip / kernels_mi.hip); n_pad = table stride
 void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s);
 void launch_kendall_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, int* d_prep,

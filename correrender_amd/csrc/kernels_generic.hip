@@ -318,6 +318,225 @@ __device__ __forceinline__ float mi_to_cc_generic(float mi) {
     return sqrtf(1.0f - e);
 }
 
+// =========================================================================================================
+// Pair-request mode: the estimator between the ensemble vectors of two arbitrary voxels per request -- the reference's
+// CorrelationComputePass request mode (src/Calculators/CorrelationCalculator.hpp:250-258, request layout
+// {xi,yi,zi,i,xj,yj,zj,j} src/Renderers/Diagram/HEBChart.hpp:166-168, Data/Shaders/Correlation/RequestsBuffer.glsl:22-36)
+// with the semantics of its CPU twin HEBChart::computeCorrelations (src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600):
+// both vectors are voxel dependent (no shared reference side), binned MI normalises with the extrema of the two
+// vectors of the pair (:556-566), Kraskov is KSG-1, NaN in either vector yields NaN (the CPU twin emits no entry).
+// One lane = one request; 2*cs gathered loads per request; same tile scheme as above (x, y, two u16 columns).
+// =========================================================================================================
+namespace {
+__host__ __device__ inline size_t pair_tile_bytes(int cs) {
+    return size_t(cs) * 64 * (2 * sizeof(float) + 2 * sizeof(uint16_t));
+}
+}  // namespace
+
+size_t pair_workspace_bytes(int cs, size_t num_requests) {
+    if (pair_tile_bytes(cs) <= kLdsTileLimit) return 0;
+    const size_t tiles = (num_requests + 63) / 64;
+    return pair_tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+}
+
+__device__ float pearson_pair(const float* x, const float* y, int cs, float half_scale_x, float half_scale_y,
+                              const uint16_t* rx, const uint16_t* ry) {
+    // computePearson2<float>(X, Y, cs) (Correlation.cpp:141-174); with rx/ry != null the inputs are the half-integer
+    // ranks 0.5 * r2 (Spearman)
+    auto X = [&](int e) { return rx ? half_scale_x * float(rx[e * 64]) : x[e * 64]; };
+    auto Y = [&](int e) { return ry ? half_scale_y * float(ry[e * 64]) : y[e * 64]; };
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanX = 0.0f, meanY = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) {
+        meanX += invN * X(e);
+        meanY += invN * Y(e);
+    }
+    float varX = 0.0f, varY = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) {
+        const float dx = X(e) - meanX, dy = Y(e) - meanY;
+        varX += invNm1 * dx * dx;
+        varY += invNm1 * dy * dy;
+    }
+    const float sdX = sqrtf(varX), sdY = sqrtf(varY);
+    float r = 0.0f;
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) r += invNm1 * ((X(e) - meanX) / sdX) * ((Y(e) - meanY) / sdY);
+    return r;
+}
+
+__device__ void ranks2_column(const float* v, uint16_t* r2, int cs) {
+#pragma unroll 1
+    for (int e = 0; e < cs; e++) {
+        const float ve = v[e * 64];
+        uint32_t s = 0;
+#pragma unroll 4
+        for (int j = 0; j < cs; j++) {
+            const float vj = v[j * 64];
+            s += (vj < ve) ? 2u : ((vj == ve) ? 1u : 0u);
+        }
+        r2[e * 64] = uint16_t(s + 1u);
+    }
+}
+
+__device__ float kendall_pair(const float* x, const float* y, int cs) {
+    int32_t discordant = 0, n1 = 0, n2 = 0;
+#pragma unroll 1
+    for (int a = 0; a < cs; a++) {
+        const float xa = x[a * 64], ya = y[a * 64];
+#pragma unroll 4
+        for (int b = a + 1; b < cs; b++) {
+            const float xb = x[b * 64], yb = y[b * 64];
+            n1 += (xa == xb) ? 1 : 0;
+            n2 += (ya == yb) ? 1 : 0;
+            discordant += ((xa < xb && ya > yb) || (xb < xa && yb > ya)) ? 1 : 0;
+        }
+    }
+    const int32_t n = cs;
+    const int32_t n0 = (n * (n - 1)) / 2;
+    const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
+    return float(numerator) / (sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2)));
+}
+
+__device__ float kraskov_pair(const float* x, const float* y, const double* __restrict__ nr,
+                              const double* __restrict__ nq, const double* __restrict__ psi, int cs, int k) {
+    const int kk = k < cs - 1 ? k : cs - 1;
+    const double factor = 1.0 / double(cs);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double sum_x = 0.0, sum_y = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < cs; i++) {
+        const double pxi = double(x[i * 64]) + nr[i], pyi = double(y[i * 64]) + nq[i];
+        double cur = -1.0, m = 0.0;
+        int cnt = 0;
+#pragma unroll 1
+        for (int pass = 0; pass < kk; pass++) {
+            m = inf;
+            int c = 0;
+#pragma unroll 2
+            for (int j = 0; j < cs; j++) {
+                const double d = fmax(fabs(pxi - (double(x[j * 64]) + nr[j])), fabs(pyi - (double(y[j * 64]) + nq[j])));
+                if (d > cur && j != i) {
+                    c = (d < m) ? 1 : (d == m ? c + 1 : c);
+                    m = fmin(m, d);
+                }
+            }
+            cnt += c;
+            if (cnt >= kk) break;
+            cur = m;
+        }
+        const double r = m - 1e-15;
+        const double lox = pxi - r, hix = pxi + r, loy = pyi - r, hiy = pyi + r;
+        int cx = 0, cy = 0;
+#pragma unroll 2
+        for (int j = 0; j < cs; j++) {
+            const double pxj = double(x[j * 64]) + nr[j], pyj = double(y[j * 64]) + nq[j];
+            cx += (pxj >= lox && pxj < hix) ? 1 : 0;
+            cy += (pyj >= loy && pyj < hiy) ? 1 : 0;
+        }
+        sum_x += factor * psi[cx > 1 ? cx : 1];
+        sum_y += factor * psi[cy > 1 ? cy : 1];
+    }
+    const double mi = -sum_x - sum_y + psi[k <= cs ? k : cs] + psi[cs];
+    const float res = float(mi);
+    return (res < 0.0f) ? 0.0f : res;
+}
+
+__global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __restrict__ members,
+                                                          const uint32_t* __restrict__ requests,
+                                                          const double* __restrict__ tables, float* __restrict__ out,
+                                                          size_t num_requests, size_t num_voxels, int xs, int ys, int cs,
+                                                          int measure, int num_bins, int k, int use_abs,
+                                                          unsigned char* __restrict__ workspace) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* tile = workspace ? workspace + size_t(blockIdx.x) * pair_tile_bytes(cs) : smem;
+    const int lane = threadIdx.x;
+    float* x = reinterpret_cast<float*>(tile) + lane;
+    float* y = x + size_t(cs) * 64;
+    uint16_t* ax = reinterpret_cast<uint16_t*>(tile + size_t(cs) * 64 * 2 * sizeof(float)) + lane;
+    uint16_t* ay = ax + size_t(cs) * 64;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const size_t tiles = (num_requests + 63) / 64;
+#pragma unroll 1
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t r = t * 64 + lane;
+        const bool active = r < num_requests;
+        uint32_t vi = 0, vj = 0;
+        if (active) {
+            const uint32_t* q = requests + r * 8;
+            vi = (q[2] * uint32_t(ys) + q[1]) * uint32_t(xs) + q[0];  // IDXS
+            vj = (q[6] * uint32_t(ys) + q[5]) * uint32_t(xs) + q[4];
+        }
+        bool is_nan = false;
+        float mn = __uint_as_float(0x7F7FFFFFu), mx = __uint_as_float(0xFF7FFFFFu);
+#pragma unroll 4
+        for (int e = 0; e < cs; e++) {
+            const float xv = load_member(members[e], vi * 4u);
+            const float yv = load_member(members[e], vj * 4u);
+            is_nan |= (xv != xv) || (yv != yv);
+            x[e * 64] = xv;
+            y[e * 64] = yv;
+            mn = fminf(mn, fminf(xv, yv));
+            mx = fmaxf(mx, fmaxf(xv, yv));
+        }
+        (void)bytes;
+        float res;
+        switch (measure) {
+            case 0: res = pearson_pair(x, y, cs, 0.f, 0.f, nullptr, nullptr); break;
+            case 1:
+                ranks2_column(x, ax, cs);
+                ranks2_column(y, ay, cs);
+                res = pearson_pair(x, y, cs, 0.5f, 0.5f, ax, ay);
+                break;
+            case 2: res = kendall_pair(x, y, cs); break;
+            case 3:
+            case 5: {
+                int total = 0;
+                const float range = mx - mn;
+#pragma unroll 2
+                for (int e = 0; e < cs; e++) {
+                    const float x01 = (x[e * 64] - mn) / range, y01 = (y[e * 64] - mn) / range;
+                    const bool valid = (x01 == x01) && (y01 == y01);
+                    int b0 = int(double(x01) * double(num_bins)), b1 = int(double(y01) * double(num_bins));
+                    b0 = b0 < 0 ? 0 : (b0 > num_bins - 1 ? num_bins - 1 : b0);
+                    b1 = b1 < 0 ? 0 : (b1 > num_bins - 1 ? num_bins - 1 : b1);
+                    ax[e * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
+                    total += valid ? 1 : 0;
+                }
+                res = binned_voxel(ax, total, total == cs, tables + (cs + 1), cs);
+                if (measure == 5) res = mi_to_cc_generic(res);
+                break;
+            }
+            default:
+                res = kraskov_pair(x, y, tables + 2 * (cs + 1), tables + 3 * cs + 2, tables, cs, k);
+                if (measure == 6) res = mi_to_cc_generic(res);
+                break;
+        }
+        if (use_abs) res = fabsf(res);
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (cs == 1) res = 1.0f;
+        if (active) out[r] = res;
+    }
+}
+
+hipError_t launch_pair_requests(const float* const* d_members, int cs, int xs, int ys, size_t num_voxels,
+                                const uint32_t* d_requests, size_t num_requests, int measure, int num_bins, int k,
+                                bool use_abs, const double* d_tables, unsigned char* d_workspace, float* d_out,
+                                hipStream_t s) {
+    if (num_requests == 0) return hipSuccess;
+    const size_t tiles = (num_requests + 63) / 64;
+    const unsigned blocks = unsigned(tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+    const bool use_lds = pair_tile_bytes(cs) <= kLdsTileLimit;
+    if (!use_lds && !d_workspace) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_request_kernel, dim3(blocks), dim3(64), use_lds ? pair_tile_bytes(cs) : 0, s, d_members,
+                       d_requests, d_tables, d_out, num_requests, num_voxels, xs, ys, cs, measure, num_bins, k,
+                       int(use_abs), use_lds ? nullptr : d_workspace);
+    return hipGetLastError();
+}
+
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {

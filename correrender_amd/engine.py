@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import CorrFieldError, CrfParams, load_library
+from ._lib import FLAG_ABSOLUTE_VALUE, CorrFieldError, CrfParams, load_library
 
 
 class Measure(enum.IntEnum):
@@ -173,6 +173,23 @@ class CorrField:
                                                  C.c_void_p(stream)))
         if keep is not None:  # the H2D copy of a host reference vector is asynchronous: keep it alive
             self._keep_ref = keep
+        return out
+
+    def compute_requests(self, measure, pairs, *, k=None, num_bins=80, absolute_value=False) -> np.ndarray:
+        """Pair-request mode (the reference's CorrelationComputePass request mode / HEBChart::computeCorrelations):
+        `pairs` is an [n, 6] integer array of (xi, yi, zi, xj, yj, zj); returns n floats."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 6)
+        xs, ys, _ = self.grid
+        req = np.zeros((pairs.shape[0], 8), dtype=np.uint32)
+        req[:, 0:3] = pairs[:, 0:3]
+        req[:, 4:7] = pairs[:, 3:6]
+        req[:, 3] = (pairs[:, 2] * ys + pairs[:, 1]) * xs + pairs[:, 0]
+        req[:, 7] = (pairs[:, 5] * ys + pairs[:, 4]) * xs + pairs[:, 3]
+        p, _ = self._params(measure, None, k, 1, num_bins, None, None, None)
+        p.flags = FLAG_ABSOLUTE_VALUE if absolute_value else 0
+        out = np.empty(req.shape[0], dtype=np.float32)
+        self._check(self._lib.crf_compute_requests(self._ctx, C.byref(p), C.c_void_p(req.ctypes.data), req.shape[0],
+                                                   out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
     # -- instrumentation ----------------------------------------------------------------------------------

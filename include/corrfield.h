@@ -68,8 +68,20 @@ typedef struct crf_params {
     const float* reference_values;   /* HOST pointer to cs floats, or NULL.  Non-NULL = CorrelationFieldMode::SEPARATE
                                         / time-lag (reference vector taken from another field, :804-813) or a vector
                                         received from another rank. */
-    int32_t reserved[4];             /* must be 0 */
+    int32_t flags;                   /* CRF_FLAG_*; only read by the pair-request entry points */
+    int32_t reserved[3];             /* must be 0 */
 } crf_params;
+
+/* useAbsoluteCorrelationMeasure of the pair-request path (HEBChartCorrelation.cpp:583-585).  The full-grid path ignores
+ * calculate_absolute_value on the CPU exactly like the reference (CorrelationCalculator.cpp:1662-1664). */
+#define CRF_FLAG_ABSOLUTE_VALUE 1
+
+/* One pair request: the estimator between the ensemble vectors of voxel (xi,yi,zi) and voxel (xj,yj,zj).  Same layout
+ * as struct CorrelationRequestData {xi,yi,zi,i,xj,yj,zj,j} (src/Renderers/Diagram/HEBChart.hpp:166-168,
+ * Data/Shaders/Correlation/RequestsBuffer.glsl:22-36); i and j (linear indices) are carried along, not read. */
+typedef struct crf_request {
+    uint32_t xi, yi, zi, i, xj, yj, zj, j;
+} crf_request;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 /* Creates a context bound to HIP device `device_ordinal`.  Fails (CRF_ERR_DEVICE) when the device is absent or is
@@ -108,6 +120,18 @@ int crf_compute(crf_context* ctx, const crf_params* params, float* host_out);
  * the reference point are used).  device_out receives xs*ys*zs floats. */
 int crf_compute_device(crf_context* ctx, const crf_params* params, const void* device_reference_values,
                        void* device_out, void* stream);
+
+/* ---- pair-request evaluation (CorrelationComputePass request mode, CorrelationCalculator.hpp:250-258; CPU twin
+ * HEBChart::computeCorrelations, src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600) ---------------------------- */
+/* out[r] = measure(X_r, Y_r) with X_r[c] = member_c[IDXS(xi,yi,zi)], Y_r[c] = member_c[IDXS(xj,yj,zj)].  Semantics of the
+ * CPU twin: Pearson/Spearman/Kendall as in the full-grid path but with both vectors per request; binned MI normalises
+ * both vectors with the extrema of the pair (:556-566); Kraskov is KSG-1; MI-CC variants map sqrt(1-exp(-2 MI));
+ * CRF_FLAG_ABSOLUTE_VALUE takes |.|; a NaN in either vector gives NaN (the CPU twin emits no entry for that pair).
+ * Read from params: measure, k, num_bins, flags. */
+int crf_compute_requests(crf_context* ctx, const crf_params* params, const crf_request* host_requests,
+                         size_t num_requests, float* host_out);
+int crf_compute_requests_device(crf_context* ctx, const crf_params* params, const void* device_requests,
+                                size_t num_requests, void* device_out, void* stream);
 
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* When enabled, every crf_compute* brackets its dominant (per-voxel) kernel with HIP events on the launch stream. */

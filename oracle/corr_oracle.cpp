@@ -19,6 +19,8 @@
  *   src/Calculators/CorrelationCalculator.cpp:781-1154  calculateCpu (driver loop, NaN rule, cs==1 rule,
  *                                                       binned normalisation, MI-CC post-map)
  *   src/Loaders/DataSet.hpp:37                 IDXS(x,y,z) = z*xs*ys + y*xs + x
+ *   src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600  pair evaluation of HEBChart::computeCorrelations (the CPU twin
+ *                                                       of the request mode): oracle_pair_requests
  *
  * PINNING STATUS
  *   Pearson / Spearman / Kendall: PINNED.  oracle/Makefile compiles the reference's own Correlation.cpp into
@@ -491,6 +493,74 @@ int oracle_correlation_field(
                 v = qnan;
             }
             out[i] = v;
+        }
+    }
+    return 0;
+}
+
+/*
+ * Pair requests (HEBChartCorrelation.cpp:493-600, the per-pair body): X[c] = fields[c][idxI], Y[c] = fields[c][idxJ];
+ * a NaN in X or Y -> no entry in the reference (:506-514,:545-551), NaN here; Spearman ranks both vectors (:515-517,
+ * :572-573); binned MI normalises X and Y with the extrema over BOTH vectors of the pair (:518-527,:553-566); Kraskov is
+ * KSG-1 (:579-581); MI-CC variants map sqrt(1-exp(-2 MI)) in fp32 (:585-592); useAbsoluteCorrelationMeasure takes |.|
+ * (:594-596).
+ */
+int oracle_pair_requests(int measure, const float* const* fields, int cs, const size_t* idxI, const size_t* idxJ,
+                         size_t numRequests, int k, int numBins, int useAbs, float* out) {
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+#pragma omp parallel
+    {
+        std::vector<float> X((size_t)cs), Y((size_t)cs), rx((size_t)cs), ry((size_t)cs);
+        RankScratch rs;
+        KendallScratch ks;
+        BinnedScratch bs;
+        KraskovScratch ms;
+#pragma omp for schedule(static)
+        for (long long r = 0; r < (long long)numRequests; r++) {
+            bool isNan = false;
+            for (int c = 0; c < cs; c++) {
+                X[size_t(c)] = fields[c][idxI[r]];
+                Y[size_t(c)] = fields[c][idxJ[r]];
+                isNan = isNan || std::isnan(X[size_t(c)]) || std::isnan(Y[size_t(c)]);
+            }
+            if (isNan) {
+                out[r] = qnan;
+                continue;
+            }
+            if (cs == 1) {
+                out[r] = 1.0f;
+                continue;
+            }
+            float v = qnan;
+            const float* xp = X.data();
+            const float* yp = Y.data();
+            if (measure == ORACLE_PEARSON) {
+                v = pearson2_f32(xp, cs, [yp](int e) { return yp[e]; });
+            } else if (measure == ORACLE_SPEARMAN) {
+                fractional_ranks(xp, rx.data(), cs, rs);
+                fractional_ranks(yp, ry.data(), cs, rs);
+                const float* ryp = ry.data();
+                v = pearson2_f32(rx.data(), cs, [ryp](int e) { return ryp[e]; });
+            } else if (measure == ORACLE_KENDALL) {
+                v = kendall_tau_b_i32(xp, yp, cs, ks);
+            } else if (measure == ORACLE_MI_BINNED || measure == ORACLE_BINNED_MI_CC) {
+                float mn = std::numeric_limits<float>::max(), mx = std::numeric_limits<float>::lowest();
+                for (int c = 0; c < cs; c++) {
+                    mn = std::min(mn, std::min(X[size_t(c)], Y[size_t(c)]));
+                    mx = std::max(mx, std::max(X[size_t(c)], Y[size_t(c)]));
+                }
+                for (int c = 0; c < cs; c++) {
+                    X[size_t(c)] = (X[size_t(c)] - mn) / (mx - mn);
+                    Y[size_t(c)] = (Y[size_t(c)] - mn) / (mx - mn);
+                }
+                v = mi_binned_f64(xp, yp, numBins, cs, bs);
+                if (measure == ORACLE_BINNED_MI_CC) v = mi_to_cc(v);
+            } else if (measure == ORACLE_MI_KRASKOV || measure == ORACLE_KMI_CC) {
+                v = mi_kraskov_f64(xp, yp, k, cs, 1, ms);
+                if (measure == ORACLE_KMI_CC) v = mi_to_cc(v);
+            }
+            if (useAbs) v = std::abs(v);
+            out[r] = v;
         }
     }
     return 0;

@@ -69,6 +69,17 @@ def main():
         data["kmi_cc__restatement"] = oracle.field(oracle_lib.KMI_CC, ens, refv, k=k)
         np.savez_compressed(OUT / f"{name}.npz", **data)
         print(f"{name}: cs={cs} voxels={ens[0].size} -> {(OUT / (name + '.npz')).stat().st_size} bytes")
+    # pair-request path (HEBChartCorrelation.cpp:493-600): reference primitives for Pearson/Spearman/Kendall,
+    # restatement for the MI estimators
+    from test_pair_requests import _case
+    ens, pairs, ii, jj = _case(32, 4242, n=300)
+    np.savez_compressed(
+        OUT / "pair_requests.npz", members=ens, pairs=pairs, idx_i=ii, idx_j=jj,
+        pearson__reference=ref.pair_requests(0, ens, ii, jj), spearman__reference=ref.pair_requests(1, ens, ii, jj),
+        kendall__reference=ref.pair_requests(2, ens, ii, jj),
+        mi_binned__restatement=oracle.pair_requests(3, ens, ii, jj, num_bins=80),
+        mi_kraskov__restatement=oracle.pair_requests(4, ens, ii, jj, k=3))
+    print("pair_requests: 300 requests, cs=32")
     # known-answer vectors (computed by the reference object code)
     x = np.array([1, 1, 2, 2, 3, 3, 4, 4], np.float32)
     y = np.array([1, 2, 2, 3, 3, 3, 5, 4], np.float32)

@@ -94,4 +94,38 @@ int ref_correlation_field(
     return 0;
 }
 
+// Pair requests with the reference's own primitives (the per-pair body of HEBChartCorrelation.cpp:493-600 for
+// measure 0 Pearson, 1 Spearman, 2 Kendall).
+int ref_pair_requests(int measure, const float* const* fieldPtrs, int cs, const size_t* idxI, const size_t* idxJ,
+                      size_t numRequests, float* out) {
+    if (measure < 0 || measure > 2) return 1;
+    std::vector<float> X((size_t)cs), Y((size_t)cs), rx((size_t)cs), ry((size_t)cs);
+    std::vector<std::pair<float, int>> rankTmp;
+    std::vector<std::pair<float, float>> joint;
+    std::vector<float> ord, yy, sortArray;
+    std::vector<std::pair<int, int>> stack;
+    for (size_t r = 0; r < numRequests; r++) {
+        bool isNan = false;
+        for (int c = 0; c < cs; c++) {
+            X[size_t(c)] = fieldPtrs[c][idxI[r]];
+            Y[size_t(c)] = fieldPtrs[c][idxJ[r]];
+            isNan = isNan || std::isnan(X[size_t(c)]) || std::isnan(Y[size_t(c)]);
+        }
+        if (isNan) {
+            out[r] = std::numeric_limits<float>::quiet_NaN();
+        } else if (cs == 1) {
+            out[r] = 1.0f;
+        } else if (measure == 0) {
+            out[r] = computePearson2<float>(X.data(), Y.data(), cs);
+        } else if (measure == 1) {
+            computeRanks(X.data(), rx.data(), rankTmp, cs);
+            computeRanks(Y.data(), ry.data(), rankTmp, cs);
+            out[r] = computePearson2<float>(rx.data(), ry.data(), cs);
+        } else {
+            out[r] = computeKendall<int32_t>(X.data(), Y.data(), cs, joint, ord, yy, sortArray, stack);
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -47,6 +47,9 @@ class Oracle:
             C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, FP, C.c_int, C.c_int, C.c_int,
             C.c_float, C.c_float, C.c_float, C.c_float, FP, C.c_int]
         lib.oracle_max_threads.restype = C.c_int
+        lib.oracle_pair_requests.restype = C.c_int
+        lib.oracle_pair_requests.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_size_t),
+                                             C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_int, FP]
 
     # -- primitives
     def pearson(self, x, y):
@@ -112,6 +115,19 @@ class Oracle:
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
 
+    def pair_requests(self, measure, members, idx_i, idx_j, *, k=3, num_bins=80, use_abs=False):
+        members = _members(members)
+        cs = len(members)
+        ii = np.ascontiguousarray(idx_i, dtype=np.uint64)
+        jj = np.ascontiguousarray(idx_j, dtype=np.uint64)
+        ptrs = (C.c_void_p * cs)(*[m.ctypes.data for m in members])
+        out = np.empty(ii.size, np.float32)
+        rc = self.lib.oracle_pair_requests(int(measure), ptrs, cs, ii.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                           jj.ctypes.data_as(C.POINTER(C.c_size_t)), ii.size, int(k), int(num_bins),
+                                           1 if use_abs else 0, _fp(out))
+        assert rc == 0
+        return out
+
 
 class Reference:
     """The reference's own object code (Pearson / Spearman / Kendall only)."""
@@ -128,6 +144,9 @@ class Reference:
         lib.ref_kendall_slow.argtypes = [FP, FP, C.c_int]
         lib.ref_correlation_field.restype = C.c_int
         lib.ref_correlation_field.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, FP, FP]
+        lib.ref_pair_requests.restype = C.c_int
+        lib.ref_pair_requests.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_size_t), C.c_size_t, FP]
 
     def pearson(self, x, y):
         x, y = _f32(x), _f32(y)
@@ -158,6 +177,22 @@ class Reference:
         rc = self.lib.ref_correlation_field(int(measure), ptrs, cs, lo, hi, _fp(ref_values), _fp(out))
         assert rc == 0
         return out
+
+
+def _ref_pair_requests(self, measure, members, idx_i, idx_j):
+    members = _members(members)
+    cs = len(members)
+    ii = np.ascontiguousarray(idx_i, dtype=np.uint64)
+    jj = np.ascontiguousarray(idx_j, dtype=np.uint64)
+    ptrs = (C.c_void_p * cs)(*[m.ctypes.data for m in members])
+    out = np.empty(ii.size, np.float32)
+    rc = self.lib.ref_pair_requests(int(measure), ptrs, cs, ii.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                    jj.ctypes.data_as(C.POINTER(C.c_size_t)), ii.size, _fp(out))
+    assert rc == 0
+    return out
+
+
+Reference.pair_requests = _ref_pair_requests
 
 
 def _f32(a):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/corrfield.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "python binding table and header diverge"
-    assert lib.crf_abi_version() == 1
+    assert lib.crf_abi_version() == 2
 
 
 def test_params_struct_layout_matches_header(tmp_path):
@@ -34,12 +34,12 @@ def test_params_struct_layout_matches_header(tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "corrfield.h"\n'
                    'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(crf_params), offsetof(crf_params, k),'
                    ' offsetof(crf_params, min_ref), offsetof(crf_params, reference_values),'
-                   ' offsetof(crf_params, reserved)); return 0;}\n')
+                   ' offsetof(crf_params, flags)); return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
     c_sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     P = _lib.CrfParams
-    assert c_sizes == [ctypes.sizeof(P), P.k.offset, P.min_ref.offset, P.reference_values.offset, P.reserved.offset]
+    assert c_sizes == [ctypes.sizeof(P), P.k.offset, P.min_ref.offset, P.reference_values.offset, P.flags.offset]
 
 
 def test_header_is_plain_c(tmp_path):

@@ -42,7 +42,7 @@ def test_status_codes(engine):
         rc = eng._lib.crf_compute(eng._ctx, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float)))
         assert rc == 1 and b"unknown measure" in eng._lib.crf_last_error(eng._ctx)
         p.measure = 0
-        p.reserved[2] = 1
+        p.reserved[1] = 1
         assert eng._lib.crf_compute(eng._ctx, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))) == 1
         assert eng._lib.crf_compute(eng._ctx, None, out.ctypes.data_as(C.POINTER(C.c_float))) == 1
         # a usable context keeps working after errors
