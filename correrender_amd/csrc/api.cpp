@@ -536,6 +536,38 @@ int crf_compute_requests(crf_context* c, const crf_params* p, const crf_request*
     return CRF_OK;
 }
 
+int crf_compute_ensemble_stat_device(crf_context* c, int stat, void* device_out, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!device_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (stat != CRF_ENSEMBLE_MEAN && stat != CRF_ENSEMBLE_SPREAD)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("unknown ensemble statistic %d", stat));
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = take_event(c);
+        e1 = take_event(c);
+    }
+    crf::LaunchInfo info;
+    hipError_t e = crf::launch_ensemble_stat(stat, c->d_member_table, c->cs, c->num_voxels,
+                                             static_cast<float*>(device_out), s, e0, e1, &info);
+    c->last_kernel = info.kernel_name ? info.kernel_name : "";
+    if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
+int crf_compute_ensemble_stat(crf_context* c, int stat, float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (int r = bind_device(c)) return r;
+    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
+    if (int r = crf_compute_ensemble_stat_device(c, stat, c->d_out, nullptr)) return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_out, c->num_voxels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
 int crf_set_profiling(crf_context* c, int enabled) {
     if (!c) return CRF_ERR_ARGUMENT;
     c->profiling = enabled != 0;

@@ -155,6 +155,23 @@ struct SortNet32<128> {
 };
 #undef CRF_CE
 
+// Correctly rounded fp32 quotients a/b for MANY numerators and ONE denominator (the voxel's standard deviation) without
+// the ~10-instruction IEEE division expansion per element: with rcp = RN(1/b) (one true division),
+//     q0 = RN(a * rcp);  rem = fma(-q0, b, a) (exact);  q = fma(rem, rcp, q0)
+// is the correctly rounded a/b (Markstein's theorem; checked against `/` on 2.4e9 operand pairs including every
+// significand of b) PROVIDED rem is exactly representable, i.e. no underflow: |a| >= 2^-100 or a == 0, b in
+// [2^-60, 2^60].  In the Pearson tail a = y_e - mean: a non-zero difference of two floats is at least half an ulp of
+// the mean, so |mean| >= 2^-70 guarantees the bound on every a.  exact_div_guard() is that per-voxel test; when it
+// fails for any lane of the wave the kernels take the plain-division path.
+__device__ __forceinline__ bool exact_div_guard(float mean, float sd) {
+    return fabsf(mean) >= 0x1p-70f && sd >= 0x1p-60f && sd <= 0x1p60f;  // false for NaN, 0, inf, tiny
+}
+__device__ __forceinline__ float exact_div(float a, float b, float rcp) {
+    const float q0 = a * rcp;
+    const float rem = fmaf(-q0, b, a);
+    return fmaf(rem, rcp, q0);
+}
+
 // The voxel side of computePearson2<float> (Correlation.cpp:141-174) for one lane: y[0..cs) in registers, a_e =
 // invNm1 * ((x_e - meanX) / sdX) prepared once per evaluation.  Sequential fp32, no contraction.
 template <int N, bool EXACT>
@@ -177,9 +194,16 @@ __device__ __forceinline__ float pearson_tail(float (&y)[N], const float* __rest
     }
     const float sdY = sqrtf(varY);
     float r = 0.0f;
+    if (__all(exact_div_guard(meanY, sdY))) {
+        const float rcp = 1.0f / sdY;
 #pragma unroll
-    for (int e = 0; e < N; e++)
-        if (EXACT || e < cs) r += prep_a[e] * (y[e] / sdY);
+        for (int e = 0; e < N; e++)
+            if (EXACT || e < cs) r += prep_a[e] * exact_div(y[e], sdY, rcp);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; e++)
+            if (EXACT || e < cs) r += prep_a[e] * (y[e] / sdY);
+    }
     return r;
 }
 

@@ -92,6 +92,10 @@ size_t generic_workspace_bytes(int cs, size_t num_voxels);
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+// ---- kernels_stats.hip: ensemble mean (kind 0) / spread (kind 1) ------------------------------------------
+hipError_t launch_ensemble_stat(int kind, const float* const* d_members, int cs, size_t num_voxels, float* d_out,
+                                hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+
 // pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}
 size_t pair_workspace_bytes(int cs, size_t num_requests);
 hipError_t launch_pair_requests(const float* const* d_members, int cs, int xs, int ys, size_t num_voxels,

@@ -145,12 +145,29 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
         sdY[v] = sqrtf(varY[v]);
         r[v] = 0.0f;
     }
+    bool guard = true;
 #pragma unroll
-    for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) {
-            const float a = prep[e];
+    for (int v = 0; v < VPT; v++) guard = guard && exact_div_guard(meanY[v], sdY[v]);
+    if (__all(guard)) {  // exact quotients through one reciprocal per voxel (crf_device.h: exact_div)
+        float rcp[VPT];
 #pragma unroll
-            for (int v = 0; v < VPT; v++) r[v] += a * (y[e][v] / sdY[v]);
+        for (int v = 0; v < VPT; v++) rcp[v] = 1.0f / sdY[v];
+#pragma unroll
+        for (int e = 0; e < CS_PAD; e++) {
+            if (EXACT || e < cs) {
+                const float a = prep[e];
+#pragma unroll
+                for (int v = 0; v < VPT; v++) r[v] += a * exact_div(y[e][v], sdY[v], rcp[v]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CS_PAD; e++) {
+            if (EXACT || e < cs) {
+                const float a = prep[e];
+#pragma unroll
+                for (int v = 0; v < VPT; v++) r[v] += a * (y[e][v] / sdY[v]);
+            }
         }
     }
     if (v0 + VPT <= num_voxels) store_vec<VPT>(out + v0, r);

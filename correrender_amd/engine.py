@@ -192,6 +192,18 @@ class CorrField:
                                                    out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def ensemble_stat(self, stat: int) -> np.ndarray:
+        """stat 0: NaN-skipping ensemble mean, 1: ensemble spread (sample std-dev); shape (zs, ys, xs)."""
+        xs, ys, zs = self.grid
+        out = np.empty((zs, ys, xs), dtype=np.float32)
+        self._check(self._lib.crf_compute_ensemble_stat(self._ctx, int(stat), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def ensemble_stat_device(self, stat: int, out, stream: int = 0):
+        self._check(self._lib.crf_compute_ensemble_stat_device(self._ctx, int(stat), C.c_void_p(out.data_ptr()),
+                                                               C.c_void_p(stream)))
+        return out
+
     # -- instrumentation ----------------------------------------------------------------------------------
     def set_profiling(self, enabled: bool):
         self._check(self._lib.crf_set_profiling(self._ctx, 1 if enabled else 0))

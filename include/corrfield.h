@@ -133,6 +133,15 @@ int crf_compute_requests(crf_context* ctx, const crf_params* params, const crf_r
 int crf_compute_requests_device(crf_context* ctx, const crf_params* params, const void* device_requests,
                                 size_t num_requests, void* device_out, void* stream);
 
+/* ---- sibling per-voxel ensemble reductions (same access pattern) ------------------------------ */
+typedef enum crf_ensemble_stat {
+    CRF_ENSEMBLE_MEAN = 0,   /* EnsembleMeanCalculator::calculateCpu,   src/Calculators/EnsembleMeanCalculator.cpp:94-138 */
+    CRF_ENSEMBLE_SPREAD = 1  /* EnsembleSpreadCalculator::calculateCpu, src/Calculators/EnsembleSpreadCalculator.cpp:94-149 */
+} crf_ensemble_stat;
+/* NaN-skipping mean / sample standard deviation over the cs members at every voxel; xs*ys*zs floats out. */
+int crf_compute_ensemble_stat(crf_context* ctx, int stat, float* host_out);
+int crf_compute_ensemble_stat_device(crf_context* ctx, int stat, void* device_out, void* stream);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* When enabled, every crf_compute* brackets its dominant (per-voxel) kernel with HIP events on the launch stream. */
 int crf_set_profiling(crf_context* ctx, int enabled);

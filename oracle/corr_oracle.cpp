@@ -19,6 +19,7 @@
  *   src/Calculators/CorrelationCalculator.cpp:781-1154  calculateCpu (driver loop, NaN rule, cs==1 rule,
  *                                                       binned normalisation, MI-CC post-map)
  *   src/Loaders/DataSet.hpp:37                 IDXS(x,y,z) = z*xs*ys + y*xs + x
+ *   src/Calculators/EnsembleMeanCalculator.cpp:110-134, EnsembleSpreadCalculator.cpp:110-145   oracle_ensemble_stat
  *   src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600  pair evaluation of HEBChart::computeCorrelations (the CPU twin
  *                                                       of the request mode): oracle_pair_requests
  *
@@ -561,6 +562,42 @@ int oracle_pair_requests(int measure, const float* const* fields, int cs, const 
             }
             if (useAbs) v = std::abs(v);
             out[r] = v;
+        }
+    }
+    return 0;
+}
+
+/*
+ * Ensemble mean (kind 0) / spread (kind 1): EnsembleMeanCalculator.cpp:110-134, EnsembleSpreadCalculator.cpp:110-145.
+ * (Those translation units need sgl/VolumeData and cannot be compiled here; plain fp32 loops, restated.)
+ */
+int oracle_ensemble_stat(int kind, const float* const* fields, int es, size_t numPoints, float* out) {
+#pragma omp parallel for schedule(static)
+    for (long long p = 0; p < (long long)numPoints; p++) {
+        int numValid = 0;
+        float mean = 0.0f;
+        for (int e = 0; e < es; e++) {
+            const float v = fields[e][p];
+            if (!std::isnan(v)) {
+                mean += v;
+                numValid++;
+            }
+        }
+        if (kind == 0) {
+            out[p] = numValid >= 1 ? mean / float(numValid) : std::numeric_limits<float>::quiet_NaN();
+        } else if (numValid > 1) {
+            mean = mean / float(numValid);
+            float varSum = 0.0f;
+            for (int e = 0; e < es; e++) {
+                const float v = fields[e][p];
+                if (!std::isnan(v)) {
+                    const float diff = mean - v;
+                    varSum += diff * diff;
+                }
+            }
+            out[p] = std::sqrt(varSum / float(numValid - 1));
+        } else {
+            out[p] = std::numeric_limits<float>::quiet_NaN();
         }
     }
     return 0;

@@ -47,6 +47,8 @@ class Oracle:
             C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, FP, C.c_int, C.c_int, C.c_int,
             C.c_float, C.c_float, C.c_float, C.c_float, FP, C.c_int]
         lib.oracle_max_threads.restype = C.c_int
+        lib.oracle_ensemble_stat.restype = C.c_int
+        lib.oracle_ensemble_stat.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, FP]
         lib.oracle_pair_requests.restype = C.c_int
         lib.oracle_pair_requests.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_size_t),
                                              C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int, C.c_int, FP]
@@ -114,6 +116,13 @@ class Oracle:
 
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
+
+    def ensemble_stat(self, kind, members):
+        members = _members(members)
+        ptrs = (C.c_void_p * len(members))(*[m.ctypes.data for m in members])
+        out = np.empty(members[0].size, np.float32)
+        assert self.lib.oracle_ensemble_stat(int(kind), ptrs, len(members), members[0].size, _fp(out)) == 0
+        return out
 
     def pair_requests(self, measure, members, idx_i, idx_j, *, k=3, num_bins=80, use_abs=False):
         members = _members(members)
