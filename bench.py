@@ -75,8 +75,14 @@ def main():
     backend = os.environ.get("CRF_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_exchange = os.environ.get("CRF_FORCE_EXCHANGE", "0") == "1"  # 1-rank process group: exercise the N>1 path
+    if world > 1 or force_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_exchange and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -87,7 +93,9 @@ def main():
     measure = ca.Measure(ca.MEASURE_IDS.index(args.measure))
     from correrender_amd.distributed import ShardedCorrField
     eng = ca.CorrField(local_rank)
-    sharded = ShardedCorrField(eng, (xs, ys, zs), cs, rank=rank, world=world, device=torch.device("cuda", local_rank))
+    sharded = ShardedCorrField(eng, (xs, ys, zs), cs, rank=rank, world=world, device=torch.device("cuda", local_rank),
+                               always_exchange=force_exchange)
+    multi = world > 1 or force_exchange
     z0, zl = sharded.z_begin, sharded.z_count
     n_local = xs * ys * zl
     n_total = xs * ys * zs
@@ -113,7 +121,7 @@ def main():
         """Steps lo..hi-1.  N > 1: the reference vectors of the next LOOKAHEAD requested points are exchanged in ONE
         collective (owners gather on their device -> RCCL all-reduce of LOOKAHEAD*cs floats) on the communication stream,
         one batch ahead of the kernels that consume them, so the exchange overlaps the evaluation of earlier steps."""
-        if world == 1:
+        if not multi:
             for i in range(lo, hi):
                 sharded.compute(measure, out, pts[i], **kwargs)
             return
@@ -125,7 +133,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -136,7 +144,7 @@ def main():
     torch.cuda.synchronize()
     t_round = max(time.perf_counter() - t_spin, 1e-4)
     rounds = torch.tensor([int(args.spinup_ms * 1e-3 / t_round) if args.spinup_ms > 0 else 0], device="cuda")
-    if world > 1:
+    if multi:
         dist.broadcast(rounds, src=0)
     for _ in range(int(rounds[0])):
         run(0, max(args.warmup, 1))
@@ -152,7 +160,7 @@ def main():
     eng.set_profiling(False)
     kernel_ms_sum, launches = eng.take_kernel_time()
     kernel_name = eng.last_kernel_name()
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -193,7 +201,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

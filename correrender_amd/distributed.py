@@ -46,7 +46,7 @@ class ShardedCorrField:
     """One rank's share of a z-slab-sharded correlation field evaluation."""
 
     def __init__(self, engine, grid: Tuple[int, int, int], cs: int, *, rank: Optional[int] = None,
-                 world: Optional[int] = None, group=None, device=None):
+                 world: Optional[int] = None, group=None, device=None, always_exchange: bool = False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -57,6 +57,9 @@ class ShardedCorrField:
         if rank is None:
             rank = dist.get_rank(group) if world > 1 else 0
         self.rank, self.world = rank, world
+        # always_exchange: run the gather + collective path even with one rank (a 1-rank RCCL group): lets the exact
+        # code path of the multi-GPU runs be exercised on a single GPU
+        self._collectives = world > 1 or (always_exchange and dist.is_available() and dist.is_initialized())
         self.xs, self.ys, self.zs = grid
         self.cs = cs
         self.z_begin, self.z_count = slab_bounds(self.zs, world, rank)
@@ -76,7 +79,7 @@ class ShardedCorrField:
         self._batch_ready = [None, None]
         self._batch_done = [None, None]
         self._cuda = self.device.type == "cuda"
-        self._stage_through_host = bool(self._cuda and world > 1 and dist.get_backend(group) == "gloo")
+        self._stage_through_host = bool(self._cuda and self._collectives and dist.get_backend(group) == "gloo")
         if self._stage_through_host:
             self._host_ref = torch.empty(cs, dtype=torch.float32)
         if self._cuda:
@@ -102,7 +105,7 @@ class ShardedCorrField:
         """min of mins / max of maxes over all members and all slabs (binned MI normalisation range)."""
         if self._minmax is None:
             mn, mx = self.engine.member_minmax()
-            if self.world > 1:
+            if self._collectives:
                 t = self._torch.tensor([mn, -mx], dtype=self._torch.float32, device=self.device)
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
                 mn, mx = float(t[0]), float(-t[1])
@@ -115,7 +118,7 @@ class ShardedCorrField:
         owner, local_z = slab_owner(self.zs, self.world, z)
         if self.rank == owner:
             self.engine.gather_reference_device(x, y, local_z, buf, stream_ptr)
-        if self.world > 1:
+        if self._collectives:
             if self._stage_through_host:
                 # rehearsal mode (gloo process group with GPU tensors, e.g. several ranks sharing one GPU): stage the
                 # cs floats through a host tensor explicitly instead of relying on gloo's own CUDA staging
@@ -171,7 +174,7 @@ class ShardedCorrField:
             for i, ((x, y, _), (owner, local_z)) in enumerate(zip(points, owners)):
                 if owner == self.rank:
                     self.engine.gather_reference_device(x, y, local_z, rows[i], stream_ptr)
-            if self.world > 1:
+            if self._collectives:
                 if self._stage_through_host:
                     self._comm_stream.synchronize()
                     host = rows[:r].cpu()
@@ -197,7 +200,7 @@ class ShardedCorrField:
         if int(measure) in _BINNED and "minmax_ref" not in kw:
             mm = self.global_minmax()
             kw = dict(kw, minmax_ref=mm, minmax_query=mm)
-        if self.world == 1 and not self._pending:
+        if not self._collectives and not self._pending:
             # single GPU: no exchange; the gather is fused into the estimator's preparation kernel
             stream_ptr = self._torch.cuda.current_stream(self.device).cuda_stream if self._cuda else 0
             self.engine.compute_device(measure, out, tuple(ref_xyz), stream=stream_ptr, **kw)
