@@ -416,7 +416,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         case CRF_SPEARMAN:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
-            if (c->cs > 64 && !c->d_todo)
+            if (c->cs > 16 && !c->d_todo)
                 CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
             e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
                                      &info);
@@ -424,7 +424,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         case CRF_KENDALL:
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
-            if (c->cs > 64 && !c->d_todo)
+            if (c->cs > 16 && !c->d_todo)
                 CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
             e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
                                     &info);

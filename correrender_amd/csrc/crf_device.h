@@ -26,6 +26,11 @@ __device__ __forceinline__ float buffer_load_f32_nt(RSRC rsrc, uint32_t byte_off
 __device__ __forceinline__ float load_member_nt(const float* base, uint32_t bytes, uint32_t byte_offset) {
     return buffer_load_f32_nt(make_member_rsrc(base, bytes), byte_offset);
 }
+// Offset that is out of range for every member descriptor (num_records <= 4 * 2^30): a load through it returns 0
+// without a memory request.  Padded slots of the guarded kernels select it (wave-uniform condition, one v_cndmask)
+// instead of branching around the load or re-reading a valid member.
+constexpr uint32_t kOutOfRangeOffset = 0xFFFFFFF0u;
+
 // plain (cacheable) gather of one value: pair requests re-use voxels, so the default cache policy is kept
 __device__ __forceinline__ float load_member(const float* base, uint32_t byte_offset) {
     typedef const float __attribute__((address_space(1)))* gptr;
@@ -179,30 +184,27 @@ __device__ __forceinline__ float pearson_tail(float (&y)[N], const float* __rest
     const float n = float(cs);
     const float invN = 1.0f / n;
     const float invNm1 = 1.0f / (n - 1.0f);
+    // Guarded use (cs < N), branch free: the caller passes y[e] = 0 and prep_a[e] = 0 for e >= cs and the deviation
+    // of those slots is forced to 0, so every pass adds +0 for them (see pearson_reg_kernel).
     float meanY = 0.0f;
 #pragma unroll
-    for (int e = 0; e < N; e++)
-        if (EXACT || e < cs) meanY += invN * y[e];
+    for (int e = 0; e < N; e++) meanY += invN * y[e];
     float varY = 0.0f;
 #pragma unroll
     for (int e = 0; e < N; e++) {
-        if (EXACT || e < cs) {
-            const float d = y[e] - meanY;
-            y[e] = d;
-            varY += invNm1 * d * d;
-        }
+        const float d = (EXACT || e < cs) ? y[e] - meanY : 0.0f;
+        y[e] = d;
+        varY += invNm1 * d * d;
     }
     const float sdY = sqrtf(varY);
     float r = 0.0f;
     if (__all(exact_div_guard(meanY, sdY))) {
         const float rcp = 1.0f / sdY;
 #pragma unroll
-        for (int e = 0; e < N; e++)
-            if (EXACT || e < cs) r += prep_a[e] * exact_div(y[e], sdY, rcp);
+        for (int e = 0; e < N; e++) r += prep_a[e] * exact_div(y[e], sdY, rcp);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; e++)
-            if (EXACT || e < cs) r += prep_a[e] * (y[e] / sdY);
+        for (int e = 0; e < N; e++) r += prep_a[e] * ((EXACT || e < cs) ? y[e] / sdY : 0.0f);
     }
     return r;
 }

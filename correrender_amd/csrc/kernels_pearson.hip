@@ -49,11 +49,14 @@ __global__ __launch_bounds__(256) void pearson_prep_kernel(RefSource src, const 
     __syncthreads();
     const float meanX = sh[0], sdX = sh[1];
     for (int e = threadIdx.x; e < cs; e += blockDim.x) prep[e] = invNm1 * ((x[e] - meanX) / sdX);
+    // padded slots of the guarded register kernels multiply by a_e = 0 (see pearson_reg_kernel)
+    for (int e = cs + threadIdx.x; e < kMaxRegisterMembers; e += blockDim.x) prep[e] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Per-voxel kernel, members resident in registers.
-//   CS_PAD  compile-time upper bound of cs (loops fully unrolled to it); EXACT: cs == CS_PAD, no guards.
+//   CS_PAD  compile-time upper bound of cs (loops fully unrolled to it); EXACT: cs == CS_PAD, no guards; otherwise
+//           CS_PAD - pad_granule(CS_PAD) < cs < CS_PAD and only the last granule is guarded.
 //   VPT     voxels per lane (1, 2 or 4) = width of each global load in dwords.
 // ---------------------------------------------------------------------------------------------------------
 template <int VPT>
@@ -97,18 +100,32 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
     *reinterpret_cast<V*>(p) = v;
 }
 
+// launch_pearson pads cs to the next multiple of this: only the last granule of a guarded instantiation can be padding
+constexpr int pad_granule(int cs_pad) { return cs_pad <= 16 ? 8 : cs_pad <= 128 ? 16 : 32; }
+
 template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES, int BLOCK = 256, bool NT = true>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
                                                                        const float* __restrict__ prep,
                                                                        float* __restrict__ out, uint32_t num_voxels,
                                                                        int cs) {
+    constexpr int kFirstGuarded = EXACT ? CS_PAD : CS_PAD - pad_granule(CS_PAD);  // slots below are always members
+    const auto is_member = [cs](int e) { return e < kFirstGuarded || e < cs; };      // folds in the unrolled loops
     const uint32_t v0 = (blockIdx.x * BLOCK + threadIdx.x) * VPT;
     const uint32_t byte_offset = v0 * 4u;       // one 32-bit offset serves all cs loads of the lane
     const uint32_t bytes = num_voxels * 4u;     // descriptor bound: lanes past the end read 0 and store nothing
+    // Guarded instantiation (cs < CS_PAD), branch free: a padded slot loads at an out-of-range offset (the value is 0
+    // and no memory request is made: crf_device.h kOutOfRangeOffset), its deviation is forced to 0 in pass 2 and its
+    // a_e is 0 (pearson_prep_kernel), so each pass adds +0 for it -- an identity on the running sums, which start at
+    // +0 and therefore are never -0.  In pass 3 exact_div(0, sd) = 0 on the fast path; the plain-division path (sd
+    // may be 0 there: 0/0) selects 0 for the pads explicitly.
     float y[CS_PAD][VPT];
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) load_vec<VPT, NT>(members[e], bytes, byte_offset, y[e]);
+        if (e < kFirstGuarded) {
+            load_vec<VPT, NT>(members[e], bytes, byte_offset, y[e]);
+        } else {
+            load_vec<VPT, NT>(members[e < cs ? e : cs - 1], bytes, e < cs ? byte_offset : kOutOfRangeOffset, y[e]);
+        }
     }
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -119,23 +136,19 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
     for (int v = 0; v < VPT; v++) meanY[v] = 0.0f;
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) {
 #pragma unroll
-            for (int v = 0; v < VPT; v++) meanY[v] += invN * y[e][v];
-        }
+        for (int v = 0; v < VPT; v++) meanY[v] += invN * y[e][v];
     }
     float varY[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; v++) varY[v] = 0.0f;
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
-        if (EXACT || e < cs) {
 #pragma unroll
-            for (int v = 0; v < VPT; v++) {
-                const float d = y[e][v] - meanY[v];
-                y[e][v] = d;  // (y_e - meanY) is needed again, bit-identically, by pass 3
-                varY[v] += invNm1 * d * d;
-            }
+        for (int v = 0; v < VPT; v++) {
+            const float d = is_member(e) ? y[e][v] - meanY[v] : 0.0f;
+            y[e][v] = d;  // (y_e - meanY) is needed again, bit-identically, by pass 3
+            varY[v] += invNm1 * d * d;
         }
     }
     float r[VPT];
@@ -154,20 +167,16 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
         for (int v = 0; v < VPT; v++) rcp[v] = 1.0f / sdY[v];
 #pragma unroll
         for (int e = 0; e < CS_PAD; e++) {
-            if (EXACT || e < cs) {
-                const float a = prep[e];
+            const float a = prep[e];
 #pragma unroll
-                for (int v = 0; v < VPT; v++) r[v] += a * exact_div(y[e][v], sdY[v], rcp[v]);
-            }
+            for (int v = 0; v < VPT; v++) r[v] += a * exact_div(y[e][v], sdY[v], rcp[v]);
         }
     } else {
 #pragma unroll
         for (int e = 0; e < CS_PAD; e++) {
-            if (EXACT || e < cs) {
-                const float a = prep[e];
+            const float a = prep[e];
 #pragma unroll
-                for (int v = 0; v < VPT; v++) r[v] += a * (y[e][v] / sdY[v]);
-            }
+            for (int v = 0; v < VPT; v++) r[v] += a * (is_member(e) ? y[e][v] / sdY[v] : 0.0f);
         }
     }
     if (v0 + VPT <= num_voxels) store_vec<VPT>(out + v0, r);
@@ -224,10 +233,10 @@ void launch_reg(const float* const* d_members, const float* d_prep, float* d_out
 template <int CS_PAD>
 void launch_reg_vpt(int vpt, const float* const* d_members, const float* d_prep, float* d_out, size_t blocks,
                     size_t num_voxels, int cs, hipStream_t s) {
-    if constexpr (CS_PAD * 4 <= 256) {
+    if constexpr (CS_PAD <= 64) {
         if (vpt == 4) return launch_reg<CS_PAD, 4>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
     }
-    if constexpr (CS_PAD * 2 <= 256) {
+    if constexpr (CS_PAD <= 64 || CS_PAD == 128) {
         if (vpt >= 2) return launch_reg<CS_PAD, 2>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
     }
     return launch_reg<CS_PAD, 1>(d_members, d_prep, d_out, blocks, num_voxels, cs, s);
@@ -261,8 +270,7 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     if (cs <= kMaxRegisterMembers) {
-        const int cs_pad = cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 48 ? 48 : cs <= 64 ? 64 : cs <= 96 ? 96
-                         : cs <= 128 ? 128 : cs <= 192 ? 192 : 256;
+        const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : (cs + 31) / 32 * 32;
         // voxels per lane.  Measured on MI355X at 256^3 x 64 (profiles/): one voxel per lane (dword loads, 93 VGPRs,
         // 5 waves/SIMD) reaches 5.7 TB/s; 2 per lane (196 VGPRs, 2 waves/SIMD) 4.9 TB/s; 4 per lane 3.4 TB/s --
         // occupancy, not load width, is what keeps HBM busy here.  CRF_PEARSON_VPT overrides for tuning experiments.
@@ -270,6 +278,7 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
         vpt = env_int("CRF_PEARSON_VPT", vpt);
         if (vpt > max_vpt) vpt = max_vpt;
         while (vpt > 1 && cs_pad * vpt > 256) vpt >>= 1;
+        if (cs_pad > 64 && cs_pad != 128) vpt = 1;  // wider loads are instantiated for the tuning sizes only
         if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 1;
         const int variant = env_int("CRF_PEARSON_VARIANT", 0);
         if (variant > 0 && cs == 64) {  // tuning experiments (tools/tune_pearson.py), one voxel per lane
@@ -296,13 +305,18 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
         const size_t blocks = (covered + per_block - 1) / per_block;
         if (blocks > 0) {
             switch (cs_pad) {
+                case 8: launch_reg_vpt<8>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 16: launch_reg_vpt<16>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 32: launch_reg_vpt<32>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 48: launch_reg_vpt<48>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 64: launch_reg_vpt<64>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 80: launch_reg_vpt<80>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 96: launch_reg_vpt<96>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 112: launch_reg_vpt<112>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 128: launch_reg_vpt<128>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 160: launch_reg_vpt<160>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 224: launch_reg_vpt<224>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 default: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
             }
         }

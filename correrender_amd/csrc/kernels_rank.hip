@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void spearman_prep_kernel(RefSource src, const
     }
     __syncthreads();
     for (int e = threadIdx.x; e < cs; e += blockDim.x) prep[e] = invNm1 * ((rx[e] - sh[0]) / sh[1]);
+    for (int e = cs + threadIdx.x; e < kMaxSortMembers; e += blockDim.x) prep[e] = 0.0f;  // pads: pearson_tail
 }
 
 // Kendall: prep as int32: [0, N) perm (slot -> member), [N, 2N) gend (slot -> last slot of its x-tie group),
@@ -138,9 +139,13 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
 
     composite_t a[N];
     {
-        float y[N];  // all loads are issued before the first use (unconditional: slots past cs re-read the last member)
+        // all loads are issued before the first use; the guarded instantiation is branch free: a slot past cs loads at
+        // kOutOfRangeOffset (value 0, no memory request) and gets the pad key, which sorts last
+        float y[N];
 #pragma unroll
-        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[EXACT ? e : (e < cs ? e : cs - 1)], bytes, byte_offset);
+        for (int e = 0; e < N; e++)
+            y[e] = load_member_nt(members[EXACT ? e : (e < cs ? e : cs - 1)], bytes,
+                                  (EXACT || e < cs) ? byte_offset : kOutOfRangeOffset);
 #pragma unroll
         for (int e = 0; e < N; e++) {
             const float yc = y[e] + 0.0f;  // -0.0 -> +0.0 so that key equality is float equality
@@ -151,36 +156,37 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
     bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
+    if constexpr (EXACT) {
+        is_nan |= composite_key(a[N - 1]) > 0xFF800000u;
+    } else {
 #pragma unroll
-    for (int p = 0; p < N; p++)
-        if (EXACT ? p == N - 1 : p == cs - 1) is_nan |= composite_key(a[p]) > 0xFF800000u;
+        for (int p = 0; p < N; p++) is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
+    }
 
+    // (the pads form a tie run of their own behind the cs real elements: scanning them too is harmless and keeps the
+    // guarded instantiation free of branches)
     // forward scan: first position of the tie run each sorted position belongs to, parked in bits 8..15 of the low word
     uint32_t run_start = 0;
 #pragma unroll
     for (int p = 0; p < N; p++) {
-        if (EXACT || p < cs) {
-            if (p > 0) {
-                const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
-                run_start = same ? run_start : uint32_t(p);
-            }
-            a[p] = composite_or_low(a[p], run_start << 8);
+        if (p > 0) {
+            const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
+            run_start = same ? run_start : uint32_t(p);
         }
+        a[p] = composite_or_low(a[p], run_start << 8);
         if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the scheduler's window: register pressure
     }
     // backward scan: last position of the run; 2*rank = start + end + 2; scatter to the member's LDS row
     uint32_t run_end = 0;
 #pragma unroll
     for (int p = N - 1; p >= 0; p--) {
-        if (EXACT || p < cs) {
-            bool same = false;
-            if (p < N - 1 && (EXACT || p + 1 < cs)) same = composite_key(a[p]) == composite_key(a[p + 1]);
-            run_end = same ? run_end : uint32_t(p);
-            const uint32_t low = composite_low(a[p]);
-            const uint32_t slot = low & 0xFFu;
-            const uint32_t start = (low >> 8) & 0xFFu;
-            rank2[slot * 64 + lane] = uint16_t(start + run_end + 2u);
-        }
+        bool same = false;
+        if (p < N - 1) same = composite_key(a[p]) == composite_key(a[p + 1]);  // real vs pad: equal only for a NaN
+        run_end = same ? run_end : uint32_t(p);
+        const uint32_t low = composite_low(a[p]);
+        const uint32_t slot = low & 0xFFu;
+        const uint32_t start = (low >> 8) & 0xFFu;
+        rank2[slot * 64 + lane] = uint16_t(start + run_end + 2u);
         if ((p & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -220,9 +226,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
 
     composite_t a[N];
     {
-        float y[N];  // slot e = e-th smallest reference value (prep[e] = member index; pads point at member 0)
+        // slot e = e-th smallest reference value (prep[e] = member index; pads point at member 0 and load at
+        // kOutOfRangeOffset: no memory request)
+        float y[N];
 #pragma unroll
-        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[prep[e]], bytes, byte_offset);
+        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[prep[e]], bytes, (EXACT || e < cs) ? byte_offset : kOutOfRangeOffset);
 #pragma unroll
         for (int e = 0; e < N; e++) {
             const float yc = y[e] + 0.0f;
@@ -233,9 +241,12 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
     bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
+    if constexpr (EXACT) {
+        is_nan |= composite_key(a[N - 1]) > 0xFF800000u;
+    } else {
 #pragma unroll
-    for (int p = 0; p < N; p++)
-        if (EXACT ? p == N - 1 : p == cs - 1) is_nan |= composite_key(a[p]) > 0xFF800000u;
+        for (int p = 0; p < N; p++) is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
+    }
 
     constexpr int W = (N + 63) / 64;
     uint64_t seen[W];
@@ -245,30 +256,31 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     uint32_t prev_key = 0;
 #pragma unroll
     for (int p = 0; p < N; p++) {
-        if (EXACT || p < cs) {
-            // ties in y: a run of t equal values contributes 0+1+...+(t-1) = t(t-1)/2
-            const uint32_t key = composite_key(a[p]);
-            if (p > 0) {
-                run = (key == prev_key) ? run + 1 : 0;
-                n2 += run;
-            }
-            prev_key = key;
-            uint32_t slot = composite_low(a[p]) & 0xFFu;
-            if ((p & 3) == 0) order_after(slot, seen[0]);  // keep the N mask computations from being hoisted en bloc
-            const uint32_t g = x_ties ? uint32_t(gend_lds[slot]) : slot;  // last slot with the same x
-            // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
-            if constexpr (W == 1) {
-                discordant += __popcll(seen[0] & (0xFFFFFFFFFFFFFFFEull << g));
-                seen[0] |= 1ull << slot;
-            } else {
-                const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
-                const uint64_t sbit = 1ull << (slot & 63u);
+        // Guarded instantiation, branch free: the pads (slots >= cs, pad key) sort behind the cs real elements in slot
+        // order, so when one is visited every seen slot is below it -- it adds no discordant pair; its tie run is
+        // masked out of n2.
+        // ties in y: a run of t equal values contributes 0+1+...+(t-1) = t(t-1)/2
+        const uint32_t key = composite_key(a[p]);
+        if (p > 0) {
+            run = ((EXACT || p < cs) && key == prev_key) ? run + 1 : 0;
+            n2 += run;
+        }
+        prev_key = key;
+        uint32_t slot = composite_low(a[p]) & 0xFFu;
+        if ((p & 3) == 0) order_after(slot, seen[0]);  // keep the N mask computations from being hoisted en bloc
+        const uint32_t g = x_ties ? uint32_t(gend_lds[slot]) : slot;  // last slot with the same x (pads: themselves)
+        // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
+        if constexpr (W == 1) {
+            discordant += __popcll(seen[0] & (0xFFFFFFFFFFFFFFFEull << g));
+            seen[0] |= 1ull << slot;
+        } else {
+            const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
+            const uint64_t sbit = 1ull << (slot & 63u);
 #pragma unroll
-                for (int w = 0; w < W; w++) {
-                    const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
-                    discordant += __popcll(seen[w] & mask);
-                    seen[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
-                }
+            for (int w = 0; w < W; w++) {
+                const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
+                discordant += __popcll(seen[w] & mask);
+                seen[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
             }
         }
         if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -297,64 +309,69 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
 // SIMD.  The kernels handle TIE-FREE voxels only (the overwhelmingly common case for continuous data); a voxel with
 // two equal values is appended to a todo list that the monolithic kernel then walks.
 // ---------------------------------------------------------------------------------------------------------
-// number of keys in the lane's sorted LDS column (stride 64 dwords) that are < key.  `tie_min` keeps the running
-// minimum of (k ^ key) over the probed lower-bound elements: it reaches 0 iff some key of the column equals `key`
-// (two VALU ops, no lane-mask bookkeeping).
-__device__ __forceinline__ uint32_t lower_bound_64(const uint32_t* col, uint32_t key, uint32_t& tie_min) {
+// number of keys in the lane's sorted LDS column (CH keys, stride 64 dwords) that are < key.  `tie_min` keeps the
+// running minimum of (k ^ key) over the probed lower-bound elements: it reaches 0 iff some key of the column equals
+// `key` (two VALU ops, no lane-mask bookkeeping).
+template <int CH>
+__device__ __forceinline__ uint32_t lower_bound_col(const uint32_t* col, uint32_t key, uint32_t& tie_min) {
     uint32_t pos = 0;
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) pos += (col[(pos + uint32_t(s) - 1u) * 64u] < key) ? uint32_t(s) : 0u;
+    for (int s = CH / 2; s >= 1; s >>= 1) pos += (col[(pos + uint32_t(s) - 1u) * 64u] < key) ? uint32_t(s) : 0u;
     const uint32_t k = col[pos * 64u];
     tie_min = min(tie_min, k ^ key);
     return pos + ((k < key) ? 1u : 0u);
 }
 
-// loads slots base..base+63 of the lane's voxel as composites (low word = slot - base), pads beyond cs
-template <bool EXACT, bool PERMUTED>
-__device__ __forceinline__ void load_chunk_64(composite_t (&a)[64], const float* const* __restrict__ members,
-                                              const int* __restrict__ perm, int base, int cs, uint32_t bytes,
-                                              uint32_t byte_offset) {
-    float y[64];  // all loads first (unconditional: slots past cs re-read a valid member), then the conversion
+// loads slots base..base+CH-1 of the lane's voxel as composites (low word = slot - base), pads beyond cs
+template <int CH, bool EXACT, bool PERMUTED>
+__device__ __forceinline__ void load_chunk(composite_t (&a)[CH], const float* const* __restrict__ members,
+                                           const int* __restrict__ perm, int base, int cs, uint32_t bytes,
+                                           uint32_t byte_offset) {
+    float y[CH];  // all loads first (slots past cs: out-of-range offset, no memory request), then the conversion
 #pragma unroll
-    for (int e = 0; e < 64; e++) {
-        const int slot = (EXACT || base + e < cs) ? base + e : cs - 1;
-        y[e] = load_member_nt(PERMUTED ? members[perm[slot]] : members[slot], bytes, byte_offset);
+    for (int e = 0; e < CH; e++) {
+        const bool real = EXACT || base + e < cs;
+        const int slot = real ? base + e : cs - 1;
+        y[e] = load_member_nt(PERMUTED ? members[perm[slot]] : members[slot], bytes,
+                              real ? byte_offset : kOutOfRangeOffset);
     }
 #pragma unroll
-    for (int e = 0; e < 64; e++) {
+    for (int e = 0; e < CH; e++) {
         const float yc = y[e] + 0.0f;
         a[e] = make_composite((EXACT || base + e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
     }
 }
 
-template <bool EXACT, int MIN_WAVES>
-__global__ __launch_bounds__(64, MIN_WAVES) void spearman_split128_kernel(const float* const* __restrict__ members,
-                                                                          const float* __restrict__ prep,
-                                                                          float* __restrict__ out, size_t num_voxels,
-                                                                          int cs, uint32_t* __restrict__ todo) {
-    __shared__ uint32_t lds[64 * 64];  // phase 1-3: sorted keys of chunk A [q][lane]; afterwards positions + histogram
-    __shared__ uint8_t slotA[64 * 64];  // slot (0..63) of the q-th smallest element of chunk A, [q][lane]
+// CH < cs <= 2*CH (CH = 64: the 65..128 member kernel; CH = 32: 33..64 members)
+template <int CH, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const float* const* __restrict__ members,
+                                                                       const float* __restrict__ prep,
+                                                                       float* __restrict__ out, size_t num_voxels,
+                                                                       int cs, uint32_t* __restrict__ todo) {
+    __shared__ uint32_t lds[CH * 64];   // phase 1-3: sorted keys of chunk A [q][lane]; afterwards positions + histogram
+    __shared__ uint8_t slotA[CH * 64];  // slot (0..CH-1) of the q-th smallest element of chunk A, [q][lane]
+    static_assert(2 * CH * 64 + (CH + 1) * 64 <= CH * 64 * 4, "positions + histogram must fit in the key array");
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const bool active = v < num_voxels;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
-    const int nB = cs - 64;
+    const int nB = cs - CH;
     bool is_nan = false;
     uint32_t tie_min = 0xFFFFFFFFu;  // min over compared key pairs of (k1 ^ k2): 0 iff the voxel has a tie
-    uint32_t infoB[64];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
+    uint32_t infoB[CH];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
     {
-        composite_t a[64];
-        load_chunk_64<true, false>(a, members, nullptr, 0, cs, bytes, byte_offset);
+        composite_t a[CH];
+        load_chunk<CH, true, false>(a, members, nullptr, 0, cs, bytes, byte_offset);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<64>::sort(a);
+        SortNet<CH>::sort(a);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int q = 0; q < 64; q++) {
+        for (int q = 0; q < CH; q++) {
             const uint32_t key = composite_key(a[q]);
             if (q > 0) tie_min = min(tie_min, key ^ prev);
             if (q == 0) is_nan |= key < 0x007FFFFFu;
-            if (q == 63) is_nan |= key > 0xFF800000u;
+            if (q == CH - 1) is_nan |= key > 0xFF800000u;
             prev = key;
             lds[q * 64 + lane] = key;
             slotA[q * 64 + lane] = uint8_t(composite_low(a[q]) & 0xFFu);
@@ -364,53 +381,53 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split128_kernel(const 
     uint32_t byte_offset_b = byte_offset;
     order_after(tie_min, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
     {
-        composite_t b[64];
-        load_chunk_64<EXACT, false>(b, members, nullptr, 64, cs, bytes, byte_offset_b);
+        composite_t b[CH];
+        load_chunk<CH, EXACT, false>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<64>::sort(b);
+        SortNet<CH>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int p = 0; p < 64; p++) {
+        for (int p = 0; p < CH; p++) {
             infoB[p] = 0u;
             if (EXACT || p < nB) {
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == 63 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CH - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
                 prev = key;
-                const uint32_t less = lower_bound_64(&lds[lane], key, tie_min);  // #{A < b_p}, 0..64
+                const uint32_t less = lower_bound_col<CH>(&lds[lane], key, tie_min);  // #{A < b_p}, 0..CH
                 infoB[p] = less | ((composite_low(b[p]) & 0xFFu) << 8);
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     // LDS is re-used from here on (this lane's binary searches are complete; LDS operations of a wave stay in order)
-    uint8_t* pos_of = reinterpret_cast<uint8_t*>(lds);  // [slot 0..127][lane]: 0-based position in the union
-    uint8_t* hist = pos_of + 128 * 64;                  // [0..64][lane]: #{b : #{A < b} == t}
+    uint8_t* pos_of = reinterpret_cast<uint8_t*>(lds);  // [slot 0..2CH-1][lane]: 0-based position in the union
+    uint8_t* hist = pos_of + 2 * CH * 64;               // [0..CH][lane]: #{b : #{A < b} == t}
 #pragma unroll
-    for (int t = 0; t <= 64; t++) hist[t * 64 + lane] = 0;
+    for (int t = 0; t <= CH; t++) hist[t * 64 + lane] = 0;
 #pragma unroll
-    for (int p = 0; p < 64; p++) {
+    for (int p = 0; p < CH; p++) {
         if (EXACT || p < nB) {
             const uint32_t less = infoB[p] & 0xFFu;
             const uint32_t slot = infoB[p] >> 8;
             const uint32_t h = hist[less * 64 + lane];
             hist[less * 64 + lane] = uint8_t(h + 1u);
-            pos_of[(64 + slot) * 64 + lane] = uint8_t(uint32_t(p) + less);
+            pos_of[(CH + slot) * 64 + lane] = uint8_t(uint32_t(p) + less);
         }
     }
     uint32_t below = 0;  // #{B < a_q} = #{b : #{A < b} <= q} (no ties)
 #pragma unroll
-    for (int q = 0; q < 64; q++) {
+    for (int q = 0; q < CH; q++) {
         below += uint32_t(hist[q * 64 + lane]);
         pos_of[uint32_t(slotA[q * 64 + lane]) * 64 + lane] = uint8_t(uint32_t(q) + below);
     }
     __builtin_amdgcn_sched_barrier(0);
-    float r[128];
+    float r[2 * CH];
 #pragma unroll
-    for (int e = 0; e < 128; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
-    float res = pearson_tail<128, EXACT>(r, prep, cs);
+    for (int e = 0; e < 2 * CH; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
+    float res = pearson_tail<2 * CH, EXACT>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
         if (tie_min == 0u && !is_nan) {
@@ -421,15 +438,16 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split128_kernel(const 
     }
 }
 
-// discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..63), two-word bitset
-__device__ __forceinline__ int32_t chunk_inversions_64(const composite_t (&a)[64], int count, bool exact) {
+// discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..CH-1), one 64-bit "seen" set
+template <int CH>
+__device__ __forceinline__ int32_t chunk_inversions(const composite_t (&a)[CH], int count, bool exact) {
     uint64_t seen = 0ull;
     int32_t inv = 0;
 #pragma unroll
-    for (int p = 0; p < 64; p++) {
+    for (int p = 0; p < CH; p++) {
         if (exact || p < count) {
             uint32_t slot = composite_low(a[p]) & 0xFFu;
-            if ((p & 3) == 0) order_after(slot, seen);  // keep the 64 mask computations from being hoisted en bloc
+            if ((p & 3) == 0) order_after(slot, seen);  // keep the mask computations from being hoisted en bloc
             inv += __popcll(seen & (0xFFFFFFFFFFFFFFFEull << slot));  // already-seen slots above this one
             seen |= 1ull << slot;
         }
@@ -437,18 +455,19 @@ __device__ __forceinline__ int32_t chunk_inversions_64(const composite_t (&a)[64
     return inv;
 }
 
-template <bool EXACT, int MIN_WAVES>
-__global__ __launch_bounds__(64, MIN_WAVES) void kendall_split128_kernel(const float* const* __restrict__ members,
-                                                                         const int* __restrict__ prep,
-                                                                         float* __restrict__ out, size_t num_voxels,
-                                                                         int cs, uint32_t* __restrict__ todo) {
-    __shared__ uint32_t keysA[64 * 64];
+template <int CH, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const float* const* __restrict__ members,
+                                                                      const int* __restrict__ prep,
+                                                                      float* __restrict__ out, size_t num_voxels,
+                                                                      int cs, uint32_t* __restrict__ todo) {
+    __shared__ uint32_t keysA[CH * 64];
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const bool active = v < num_voxels;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
-    const int nB = cs - 64;
-    const bool x_ties = prep[2 * 128 + 1] != 0;  // x-tie groups may straddle the chunks: left to the monolithic kernel
+    const int nB = cs - CH;
+    // prep layout of launch_kendall_prep with n_pad = 2*CH; x-tie groups may straddle the chunks: monolithic kernel
+    const bool x_ties = prep[2 * (2 * CH) + 1] != 0;
     if (x_ties) {
         if (active) todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         return;
@@ -457,51 +476,51 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split128_kernel(const f
     uint32_t tie_min = 0xFFFFFFFFu;
     int32_t discordant = 0;
     {
-        composite_t a[64];
-        load_chunk_64<true, true>(a, members, prep, 0, cs, bytes, byte_offset);
+        composite_t a[CH];
+        load_chunk<CH, true, true>(a, members, prep, 0, cs, bytes, byte_offset);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<64>::sort(a);
+        SortNet<CH>::sort(a);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int q = 0; q < 64; q++) {
+        for (int q = 0; q < CH; q++) {
             const uint32_t key = composite_key(a[q]);
             if (q > 0) tie_min = min(tie_min, key ^ prev);
             if (q == 0) is_nan |= key < 0x007FFFFFu;
-            if (q == 63) is_nan |= key > 0xFF800000u;
+            if (q == CH - 1) is_nan |= key > 0xFF800000u;
             prev = key;
             keysA[q * 64 + lane] = key;
         }
-        discordant += chunk_inversions_64(a, 64, true);
+        discordant += chunk_inversions<CH>(a, CH, true);
     }
     __builtin_amdgcn_sched_barrier(0);
     uint32_t byte_offset_b = byte_offset;
     order_after(discordant, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
     order_after(tie_min, byte_offset_b);
     {
-        composite_t b[64];
-        load_chunk_64<EXACT, true>(b, members, prep, 64, cs, bytes, byte_offset_b);
+        composite_t b[CH];
+        load_chunk<CH, EXACT, true>(b, members, prep, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<64>::sort(b);
+        SortNet<CH>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int p = 0; p < 64; p++) {
+        for (int p = 0; p < CH; p++) {
             if (EXACT || p < nB) {
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == 63 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CH - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
                 prev = key;
                 // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
-                discordant += 64 - int32_t(lower_bound_64(&keysA[lane], key, tie_min));
+                discordant += CH - int32_t(lower_bound_col<CH>(&keysA[lane], key, tie_min));
             }
         }
-        discordant += chunk_inversions_64(b, nB, EXACT);
+        discordant += chunk_inversions<CH>(b, nB, EXACT);
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
-    const int32_t n1 = prep[2 * 128];  // 0 here
+    const int32_t n1 = prep[2 * (2 * CH)];  // 0 here
     const int32_t numerator = n0 - n1 - 2 * discordant;  // n2 = 0: no ties in y
     const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
     float res = float(numerator) / denominator;
@@ -517,7 +536,18 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split128_kernel(const f
 
 namespace {
 
-// tuning switches (tools/tune_pearson.py): CRF_RANK_EXACT=0 forces the guarded instantiations
+// tuning switches (tools/tune_pearson.py): CRF_RANK_SPLIT64=1 uses the split-sort kernels for 33..64 members too
+bool env_split64() {
+    const char* v = getenv("CRF_RANK_SPLIT64");
+    return v && *v == '1';
+}
+
+bool env_split64_default_on() {
+    const char* v = getenv("CRF_RANK_SPLIT64");
+    return !(v && *v == '0');
+}
+
+// CRF_RANK_EXACT=0 forces the guarded instantiations
 bool env_exact() {
     const char* v = getenv("CRF_RANK_EXACT");
     return !(v && *v == '0');
@@ -550,6 +580,12 @@ void launch_kendall_n(const float* const* d_members, const int* d_prep, float* d
 }
 
 int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
+
+int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+bool env_flag(const char* name) { return env_int(name, 0) == 1; }
 
 // waves/SIMD the 64-member kernels are compiled for (register cap 512/256/168); CRF_RANK_WAVES overrides for tuning.
 int env_waves(int fallback) {
@@ -585,8 +621,40 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
-        case 32: launch_spearman_n<32, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+        case 32:
+            // measured at 256^3: cs = 32: monolithic unguarded 0.62-0.66 ms, split 0.65 ms; cs = 24: monolithic guarded
+            // 1.2-2.0 ms, split 0.56 ms; cs = 20: 1.2-2.1 ms vs 0.49 ms
+            if (d_todo && cs > 16 && (cs < 32 || env_flag("CRF_RANK_SPLIT32"))) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                hipLaunchKernelGGL((spearman_split_kernel<16, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                   d_prep, d_out, num_voxels, cs, d_todo);
+                launch_spearman_n<32, 4>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                split = true;
+                break;
+            }
+            switch (env_int("CRF_RANK_WAVES32", 4)) {
+                case 2: launch_spearman_n<32, 2>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+                case 3: launch_spearman_n<32, 3>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+                default: launch_spearman_n<32, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
+            }
+            break;
         case 64:
+            // measured at 256^3 (profiles/tuning_r01.md): cs = 64: monolithic unguarded 1.75 ms vs split 1.87-1.96 ms;
+            // cs = 48: monolithic guarded 5.26 ms vs split 1.65 ms; cs = 40: 5.45 ms vs 1.43 ms
+            if (d_todo && cs > 32 && (cs < 64 || env_split64())) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                if (cs == 64 && env_exact() && getenv("CRF_RANK_EXACT"))
+                    hipLaunchKernelGGL((spearman_split_kernel<32, true, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((spearman_split_kernel<32, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
+                launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                split = true;
+                break;
+            }
             switch (env_waves(2)) {
                 case 1: launch_spearman_n<64, 1>(d_members, d_prep, d_out, num_voxels, cs, s); break;
                 case 3: launch_spearman_n<64, 3>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -600,10 +668,10 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const unsigned blocks = unsigned((num_voxels + 63) / 64);
                 if (cs == 128 && env_exact())
-                    hipLaunchKernelGGL((spearman_split128_kernel<true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                    hipLaunchKernelGGL((spearman_split_kernel<64, true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
                                        d_prep, d_out, num_voxels, cs, d_todo);
                 else
-                    hipLaunchKernelGGL((spearman_split128_kernel<false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                    hipLaunchKernelGGL((spearman_split_kernel<64, false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
                                        d_prep, d_out, num_voxels, cs, d_todo);
                 launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
                 split = true;
@@ -613,7 +681,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info) info->kernel_name = split ? "spearman_split128_kernel" : "spearman_kernel";
+    if (info) info->kernel_name = split ? "spearman_split_kernel" : "spearman_kernel";
     return hipGetLastError();
 }
 
@@ -634,8 +702,40 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
-        case 32: launch_kendall_n<32, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
+        case 32:
+            // measured at 256^3: cs = 32: split 0.55 ms vs monolithic 0.63-1.23 ms; cs = 24: 0.46 vs 1.0-2.4 ms;
+            // cs = 20: 0.41 vs 1.0-2.6 ms.  CRF_RANK_SPLIT32=0 selects the monolithic kernel.
+            if (d_todo && cs > 16 && env_int("CRF_RANK_SPLIT32", 1) != 0) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                hipLaunchKernelGGL((kendall_split_kernel<16, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                   prep, d_out, num_voxels, cs, d_todo);
+                launch_kendall_n<32, 4>(d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                split = true;
+                break;
+            }
+            switch (env_int("CRF_RANK_WAVES32", 4)) {
+                case 2: launch_kendall_n<32, 2>(d_members, prep, d_out, num_voxels, cs, s); break;
+                case 3: launch_kendall_n<32, 3>(d_members, prep, d_out, num_voxels, cs, s); break;
+                default: launch_kendall_n<32, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
+            }
+            break;
         case 64:
+            // measured at 256^3: cs = 64: split (guarded) 1.49 ms vs monolithic 2.64 ms; cs = 48: 1.24 vs 4.22 ms;
+            // cs = 40: 1.05 vs 4.12 ms.  CRF_RANK_SPLIT64=0 selects the monolithic kernel.
+            if (d_todo && cs > 32 && env_split64_default_on()) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+                if (cs == 64 && env_exact() && getenv("CRF_RANK_EXACT"))
+                    hipLaunchKernelGGL((kendall_split_kernel<32, true, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((kendall_split_kernel<32, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       prep, d_out, num_voxels, cs, d_todo);
+                launch_kendall_n<64, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                split = true;
+                break;
+            }
             switch (env_waves(1)) {
                 case 3: launch_kendall_n<64, 3>(d_members, prep, d_out, num_voxels, cs, s); break;
                 case 2: launch_kendall_n<64, 2>(d_members, prep, d_out, num_voxels, cs, s); break;
@@ -649,10 +749,10 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                 // the guarded instantiation compiles to 226 VGPRs without scratch and is the fastest for every cs
                 // (4.8 ms at 256^3 x 128 vs 12.8 ms unguarded, 13.9-27.7 ms monolithic)
                 if (cs == 128 && env_exact() && getenv("CRF_RANK_EXACT"))
-                    hipLaunchKernelGGL((kendall_split128_kernel<true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                    hipLaunchKernelGGL((kendall_split_kernel<64, true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
                                        prep, d_out, num_voxels, cs, d_todo);
                 else
-                    hipLaunchKernelGGL((kendall_split128_kernel<false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
+                    hipLaunchKernelGGL((kendall_split_kernel<64, false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
                                        prep, d_out, num_voxels, cs, d_todo);
                 launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
                 split = true;
@@ -662,7 +762,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
             break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info) info->kernel_name = split ? "kendall_split128_kernel" : "kendall_kernel";
+    if (info) info->kernel_name = split ? "kendall_split_kernel" : "kendall_kernel";
     return hipGetLastError();
 }
 

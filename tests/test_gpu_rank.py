@@ -29,7 +29,7 @@ def _check(engine, oracle, ens, ref_xyz, measure, omeasure, what, reference_valu
 
 
 @pytest.mark.parametrize("measure,omeasure", MEASURES)
-@pytest.mark.parametrize("cs", [2, 3, 7, 16, 17, 32, 33, 50, 64, 65, 100, 128])
+@pytest.mark.parametrize("cs", [2, 3, 7, 16, 17, 20, 24, 32, 33, 40, 48, 50, 64, 65, 72, 96, 100, 112, 128])
 def test_rank_member_counts(engine, oracle, measure, omeasure, cs):
     ens = synth.box_ensemble(20, 12, 9, cs, seed=100 + cs)
     _check(engine, oracle, ens, (5, 6, 4), measure, omeasure, f"{measure.name} cs={cs}")
@@ -40,7 +40,7 @@ def test_rank_ties_everywhere(engine, oracle, measure, omeasure):
     """Heavily tied data (values rounded to a few levels): fractional ranks, tau-b tie terms, x-tie groups, the
     reference's ignored joint ties."""
     rng = np.random.default_rng(3)
-    for cs in (8, 24, 64, 100, 128):   # > 64: split-sort kernels + deferred (tie) list handled by the monolithic pass
+    for cs in (8, 20, 24, 48, 64, 100, 128):   # > 16: split-sort kernels + deferred (tie) list handled by the monolithic pass
         ens = np.round(rng.standard_normal((cs, 4, 8, 16)) * 1.5).astype(np.float32)
         ens[:, 0, 0, 0] = 2.0                       # all-equal voxel: 0/0 -> NaN (Kendall), NaN (Spearman)
         ens[:, 0, 0, 1] = np.arange(cs)             # strictly increasing
@@ -53,6 +53,22 @@ def test_rank_ties_everywhere(engine, oracle, measure, omeasure):
         # constant reference vector: n0 - n1 = 0 -> division by zero -> NaN or +-inf exactly as the reference
         _check(engine, oracle, ens, None, measure, omeasure, f"{measure.name} ties/const-ref cs={cs}",
                reference_values=np.full(cs, 1.5, np.float32))
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+@pytest.mark.parametrize("cs", [24, 32, 48, 64, 100])
+def test_rank_sparse_ties(engine, oracle, measure, omeasure, cs):
+    """Continuous data with a tie in a few voxels only: the split-sort kernels answer the tie-free voxels and defer
+    the rest to the monolithic kernel through the todo list -- both paths must land in the same output field."""
+    rng = np.random.default_rng(cs)
+    ens = rng.standard_normal((cs, 6, 8, 16)).astype(np.float32)
+    ens[cs - 1, 1, 2, 3] = ens[0, 1, 2, 3]            # tie across the two chunks
+    ens[1, 2, 2, 3] = ens[0, 2, 2, 3]                 # tie inside chunk A
+    ens[cs - 2, 3, 2, 3] = ens[cs - 1, 3, 2, 3]       # tie inside chunk B
+    ens[3, 5, 7, 15] = ens[cs // 2, 5, 7, 15]         # last voxel
+    ens[:, 4, 0, 0] = 1.0                             # constant voxel
+    _check(engine, oracle, ens, (5, 3, 2), measure, omeasure, f"{measure.name} sparse ties cs={cs}")
+    _check(engine, oracle, ens, (3, 2, 1), measure, omeasure, f"{measure.name} sparse ties, tied ref cs={cs}")
 
 
 def test_kendall_known_answer(engine):
