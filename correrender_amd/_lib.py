@@ -39,6 +39,8 @@ class CrfRequest(C.Structure):
 
 
 FLAG_ABSOLUTE_VALUE = 1
+FLAG_SYMMETRIC = 2
+FLAG_REFERENCE_FROM_SECONDARY = 4
 
 
 # every symbol include/corrfield.h declares: name -> (restype, argtypes)
@@ -52,6 +54,9 @@ SYMBOLS = {
     "crf_upload_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_bind_members_device": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crf_upload_secondary_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_bind_secondary_members_device": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_gather_reference": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "crf_gather_reference_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
     "crf_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),

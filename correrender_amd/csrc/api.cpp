@@ -43,6 +43,12 @@ struct crf_context {
     std::vector<const float*> members;  // cs device pointers (owned or borrowed)
     const float** d_member_table = nullptr;
     int max_vpt = 1;
+    // secondary members (second scalar field of the SEPARATE / SEPARATE_SYMMETRIC modes), optional
+    void* sec_owned_block = nullptr;
+    std::vector<const float*> sec_members;
+    const float** d_sec_table = nullptr;
+    bool sec_minmax_valid = false;
+    float sec_min_v = 0.f, sec_max_v = 0.f;
     // scratch
     float* d_ref = nullptr;    // cs reference values
     float* d_prep = nullptr;   // crf::kPrepBytes
@@ -89,6 +95,13 @@ void release_members(crf_context* c) {
     c->owned_block = nullptr;
     c->members.clear();
     c->minmax_valid = false;
+}
+
+void release_secondary(crf_context* c) {
+    if (c->sec_owned_block) (void)hipFree(c->sec_owned_block);
+    c->sec_owned_block = nullptr;
+    c->sec_members.clear();
+    c->sec_minmax_valid = false;
 }
 
 int alignment_vpt(const void* p) {
@@ -216,7 +229,9 @@ void crf_destroy(crf_context* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_members(c);
+    release_secondary(c);
     if (c->d_member_table) (void)hipFree(c->d_member_table);
+    if (c->d_sec_table) (void)hipFree(c->d_sec_table);
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_prep) (void)hipFree(c->d_prep);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -244,7 +259,10 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
         return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) larger than 4 GiB is not supported; shard it");
     if (int r = bind_device(c)) return r;
     release_members(c);
+    release_secondary(c);
     if (c->d_member_table) (void)hipFree(c->d_member_table);
+    if (c->d_sec_table) (void)hipFree(c->d_sec_table);
+    c->d_sec_table = nullptr;
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -321,6 +339,113 @@ int crf_member_minmax(crf_context* c, float* out_min, float* out_max) {
     return CRF_OK;
 }
 
+static int install_secondary_table(crf_context* c) {
+    if (!c->d_sec_table)
+        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_sec_table), sizeof(float*) * size_t(c->cs)));
+    CRF_HIP(c, hipMemcpyAsync(c->d_sec_table, c->sec_members.data(), sizeof(float*) * size_t(c->cs),
+                              hipMemcpyHostToDevice, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    c->sec_minmax_valid = false;
+    return CRF_OK;
+}
+
+int crf_upload_secondary_members(crf_context* c, const float* const* host_members) {
+    if (!c || !host_members) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    for (int i = 0; i < c->cs; i++)
+        if (!host_members[i]) return fail(c, CRF_ERR_ARGUMENT, fmt("secondary member %d is a null pointer", i));
+    if (int r = bind_device(c)) return r;
+    release_secondary(c);
+    const size_t stride = (c->num_voxels + 63) & ~size_t(63);
+    CRF_HIP(c, hipMalloc(&c->sec_owned_block, stride * sizeof(float) * size_t(c->cs)));
+    c->sec_members.resize(size_t(c->cs));
+    for (int i = 0; i < c->cs; i++) {
+        float* dst = static_cast<float*>(c->sec_owned_block) + stride * size_t(i);
+        c->sec_members[size_t(i)] = dst;
+        CRF_HIP(c, hipMemcpyAsync(dst, host_members[i], c->num_voxels * sizeof(float), hipMemcpyHostToDevice,
+                                  c->stream));
+    }
+    return install_secondary_table(c);
+}
+
+int crf_bind_secondary_members_device(crf_context* c, const void* const* device_members) {
+    if (!c || !device_members) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    for (int i = 0; i < c->cs; i++)
+        if (!device_members[i]) return fail(c, CRF_ERR_ARGUMENT, fmt("secondary member %d is a null pointer", i));
+    if (int r = bind_device(c)) return r;
+    release_secondary(c);
+    c->sec_members.resize(size_t(c->cs));
+    for (int i = 0; i < c->cs; i++) c->sec_members[size_t(i)] = static_cast<const float*>(device_members[i]);
+    return install_secondary_table(c);
+}
+
+int crf_secondary_member_minmax(crf_context* c, float* out_min, float* out_max) {
+    if (int r = check_ready(c)) return r;
+    if (!out_min || !out_max) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (c->sec_members.empty()) return fail(c, CRF_ERR_STATE, "no secondary members are bound");
+    if (!c->sec_minmax_valid) {
+        if (int r = bind_device(c)) return r;
+        CRF_HIP(c, crf::launch_minmax(c->d_sec_table, c->cs, c->num_voxels, c->d_minmax, c->stream));
+        uint32_t keys[2];
+        CRF_HIP(c, hipMemcpyAsync(keys, c->d_minmax, sizeof keys, hipMemcpyDeviceToHost, c->stream));
+        CRF_HIP(c, hipStreamSynchronize(c->stream));
+        c->sec_min_v = crf::minmax_key_to_float(keys[0]);
+        c->sec_max_v = crf::minmax_key_to_float(keys[1]);
+        c->sec_minmax_valid = true;
+    }
+    *out_min = c->sec_min_v;
+    *out_max = c->sec_max_v;
+    return CRF_OK;
+}
+
+static int ensure_workspace(crf_context* c, size_t need) {
+    if (need > c->workspace_bytes) {
+        if (c->d_workspace) (void)hipFree(c->d_workspace);
+        c->d_workspace = nullptr;
+        c->workspace_bytes = 0;
+        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_workspace), need));
+        c->workspace_bytes = need;
+    }
+    return CRF_OK;
+}
+
+// CRF_FLAG_SYMMETRIC: measure(primary members at v, secondary members at v) for every voxel v
+static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hipStream_t s) {
+    if (c->sec_members.empty())
+        return fail(c, CRF_ERR_STATE, "CRF_FLAG_SYMMETRIC needs secondary members (crf_upload_secondary_members)");
+    if (c->cs > crf::kMaxGenericMembers)
+        return fail(c, CRF_ERR_UNSUPPORTED, fmt("the symmetric mode supports at most %d members", crf::kMaxGenericMembers));
+    if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
+    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || (p->k > c->cs && c->cs > 1)))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = take_event(c);
+        e1 = take_event(c);
+        (void)hipEventRecord(e0, s);
+    }
+    hipError_t e = hipErrorNotSupported;
+    if (p->measure == CRF_PEARSON) {
+        e = crf::launch_pearson_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, out, s);
+        c->last_kernel = "pearson_symmetric_kernel";
+    }
+    if (e == hipErrorNotSupported) {
+        if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, c->num_voxels))) return r;
+        const crf::PairArgs a{p->measure, p->num_bins, p->k, 0, 1, p->min_ref, p->max_ref, p->min_query, p->max_query};
+        e = crf::launch_pair_requests(c->d_member_table, c->d_sec_table, c->cs, c->xs, c->ys, c->num_voxels, nullptr,
+                                      c->num_voxels, a, c->d_tables, c->d_workspace, out, s);
+        c->last_kernel = "pair_request_kernel";
+    }
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, s);
+        c->ev_pending.emplace_back(e0, e1);
+    }
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
 static int ref_voxel(crf_context* c, int x, int y, int z, size_t* voxel) {
     if (x < 0 || y < 0 || z < 0 || x >= c->xs || y >= c->ys || z >= c->zs)
         return fail(c, CRF_ERR_ARGUMENT,
@@ -359,10 +484,19 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     float* out = static_cast<float*>(device_out);
+    if (p->flags & CRF_FLAG_SYMMETRIC) return compute_symmetric(c, p, out, s);
 
     // 1. reference vector (CorrelationCalculator.cpp:802-818): a device array, a host array (copied stream-ordered),
     //    or the reference point -- then the gather is fused into the estimator's preparation kernel.
     crf::RefSource ref{static_cast<const float*>(device_reference_values), 0};
+    if (!ref.values && (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY)) {
+        if (c->sec_members.empty())
+            return fail(c, CRF_ERR_STATE, "CRF_FLAG_REFERENCE_FROM_SECONDARY needs secondary members");
+        size_t voxel;
+        if (int r = ref_voxel(c, p->ref_x, p->ref_y, p->ref_z, &voxel)) return r;
+        CRF_HIP(c, crf::launch_gather_reference(c->d_sec_table, c->cs, voxel, c->d_ref, s));
+        ref.values = c->d_ref;
+    }
     if (!ref.values) {
         if (p->reference_values) {
             CRF_HIP(c, hipMemcpyAsync(c->d_ref, p->reference_values, sizeof(float) * size_t(c->cs),
@@ -489,18 +623,11 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
         return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const size_t need = crf::pair_workspace_bytes(c->cs, num_requests);
-    if (need > c->workspace_bytes) {
-        if (c->d_workspace) (void)hipFree(c->d_workspace);
-        c->d_workspace = nullptr;
-        c->workspace_bytes = 0;
-        CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_workspace), need));
-        c->workspace_bytes = need;
-    }
-    hipError_t e = crf::launch_pair_requests(c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
-                                             static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
-                                             p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) != 0, c->d_tables,
-                                             c->d_workspace, static_cast<float*>(device_out), s);
+    if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, num_requests))) return r;
+    const crf::PairArgs a{p->measure, p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) ? 1 : 0, 0, 0.f, 0.f, 0.f, 0.f};
+    hipError_t e = crf::launch_pair_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                             static_cast<const uint32_t*>(device_requests), num_requests, a,
+                                             c->d_tables, c->d_workspace, static_cast<float*>(device_out), s);
     c->last_kernel = "pair_request_kernel";
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
     return CRF_OK;

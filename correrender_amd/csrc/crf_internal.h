@@ -96,12 +96,22 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
 hipError_t launch_ensemble_stat(int kind, const float* const* d_members, int cs, size_t num_voxels, float* d_out,
                                 hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
-// pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}
+// pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}; voxel i is read from
+// d_members_i, voxel j from d_members_j.  d_requests == nullptr: request r = voxel pair (r, r) (symmetric field mode).
+struct PairArgs {
+    int measure, num_bins, k, use_abs;
+    int fixed_ranges;  // binned MI: 0 = normalise with the pair's own extrema (HEBChart), 1 = with the ranges below
+    float min_ref, max_ref, min_query, max_query;
+};
 size_t pair_workspace_bytes(int cs, size_t num_requests);
-hipError_t launch_pair_requests(const float* const* d_members, int cs, int xs, int ys, size_t num_voxels,
-                                const uint32_t* d_requests, size_t num_requests, int measure, int num_bins, int k,
-                                bool use_abs, const double* d_tables, unsigned char* d_workspace, float* d_out,
-                                hipStream_t s);
+hipError_t launch_pair_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
+                                size_t num_voxels, const uint32_t* d_requests, size_t num_requests, const PairArgs& a,
+                                const double* d_tables, unsigned char* d_workspace, float* d_out, hipStream_t s);
+// symmetric field mode, Pearson, members resident in registers (kernels_pearson.hip); hipErrorNotSupported above
+// kMaxSymmetricRegisterMembers (the caller then uses launch_pair_requests)
+constexpr int kMaxSymmetricRegisterMembers = 128;
+hipError_t launch_pearson_symmetric(const float* const* d_members_ref, const float* const* d_members_query, int cs,
+                                    size_t num_voxels, float* d_out, hipStream_t s);
 // preparation launchers shared with the generic path (kernels_rank.hip / kernels_mi.hip); n_pad = table stride
 void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s);
 void launch_kendall_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, int* d_prep,

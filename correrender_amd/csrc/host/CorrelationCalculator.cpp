@@ -246,6 +246,19 @@ void CorrelationCalculator::ensureMembersResident(int timeStepIdx, int ensembleI
     residentE = isEnsembleMode ? -1 : fixedIdx;
 }
 
+// SEPARATE_SYMMETRIC: the second field's members (fieldEntriesSecondary, CorrelationCalculator.cpp:1182-1216).  Uploaded
+// per evaluation: the mode is rare and a second residency cache would have to follow the primary one's invalidation.
+void CorrelationCalculator::uploadSecondaryMembers(int timeStepIdx, int ensembleIdx, int cs) {
+    const std::string& fieldName = scalarFieldNames.at(size_t(fieldIndex2Gui));
+    std::vector<HostCacheEntry> fieldEntries;
+    std::vector<const float*> fields;
+    for (int fieldIdx = 0; fieldIdx < cs; fieldIdx++) {
+        fieldEntries.push_back(getFieldEntryCpu(fieldName, fieldIdx, timeStepIdx, ensembleIdx));
+        fields.push_back(fieldEntries.back()->data<float>());
+    }
+    if (crf_upload_secondary_members(ctx, fields.data())) throwBackendError("calculateCpu");
+}
+
 void CorrelationCalculator::calculateCpu(int timeStepIdx, int ensembleIdx, float* buffer) {
     const int xs = volumeData->getGridSizeX();
     const int ys = volumeData->getGridSizeY();
@@ -301,6 +314,16 @@ void CorrelationCalculator::calculateCpu(int timeStepIdx, int ensembleIdx, float
         params.max_ref = maxFieldValRef;
         params.min_query = minFieldValQuery;
         params.max_query = maxFieldValQuery;
+    }
+
+    // SEPARATE_SYMMETRIC: the reference's calculateCpu has no branch for it (it evaluates the SINGLE mode); its
+    // accelerator path correlates the two fields voxel by voxel (:1182-1229, CorrelationMain.glsl:10-15) and that is
+    // what this backend computes: X = scalarFields (field 1), Y = scalarFieldsSecondary (field 2).
+    if (correlationFieldMode == CorrelationFieldMode::SEPARATE_SYMMETRIC) {
+        uploadSecondaryMembers(timeStepIdx, ensembleIdx, cs);
+        params.flags |= CRF_FLAG_SYMMETRIC;
+        std::swap(params.min_ref, params.min_query);  // the ranges above are (field 2, field 1): X is field 1 here
+        std::swap(params.max_ref, params.max_query);
     }
 
     crf_set_profiling(ctx, 1);

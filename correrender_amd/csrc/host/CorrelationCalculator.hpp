@@ -97,6 +97,7 @@ protected:
 
 private:
     void ensureMembersResident(int timeStepIdx, int ensembleIdx, int cs);
+    void uploadSecondaryMembers(int timeStepIdx, int ensembleIdx, int cs);
     [[noreturn]] void throwBackendError(const char* where);
 
     int device;

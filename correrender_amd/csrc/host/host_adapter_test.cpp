@@ -163,6 +163,13 @@ static int testCompute(const char* inPath, const std::string& outDir) {
             eval("pearson_separate_lag0", tFixed, 0);
         }
     }
+    if (nf > 1) {  // SEPARATE_SYMMETRIC: field 1 vs field 2 voxel by voxel
+        calc->setSettings(SettingsMap{{"correlation_measure_type", "kendall"}, {"use_time_lag_correlations", "0"},
+                                       {"correlation_field_mode", "Separate Symmetric"}});
+        eval("kendall_symmetric", tFixed, 0);
+        calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_binned"}});
+        eval("binned_symmetric", tFixed, 0);
+    }
     std::printf("COMPUTE-OK kernel_ms=%.4f\n", calc->getLastKernelTimeMs());
     return 0;
 }

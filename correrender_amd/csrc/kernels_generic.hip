@@ -445,12 +445,17 @@ __device__ float kraskov_pair(const float* x, const float* y, const double* __re
     return (res < 0.0f) ? 0.0f : res;
 }
 
-__global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __restrict__ members,
+// members_i / members_j: the member sets the first / second voxel of a request is read from (the same table for the
+// request mode; primary / secondary field for the symmetric field mode).  requests == nullptr: request r is the
+// voxel pair (r, r) -- SEPARATE_SYMMETRIC, CorrelationMain.glsl:10-15.  a.fixed_ranges: binned MI normalises with
+// the given global ranges (CorrelationCalculator.cpp:820-846) instead of the pair's own extrema (HEBChart).
+__global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __restrict__ members_i,
+                                                          const float* const* __restrict__ members_j,
                                                           const uint32_t* __restrict__ requests,
                                                           const double* __restrict__ tables, float* __restrict__ out,
                                                           size_t num_requests, size_t num_voxels, int xs, int ys, int cs,
-                                                          int measure, int num_bins, int k, int use_abs,
-                                                          unsigned char* __restrict__ workspace) {
+                                                          PairArgs a, unsigned char* __restrict__ workspace) {
+    const int measure = a.measure, num_bins = a.num_bins, k = a.k, use_abs = a.use_abs;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* tile = workspace ? workspace + size_t(blockIdx.x) * pair_tile_bytes(cs) : smem;
     const int lane = threadIdx.x;
@@ -466,16 +471,20 @@ __global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __
         const bool active = r < num_requests;
         uint32_t vi = 0, vj = 0;
         if (active) {
-            const uint32_t* q = requests + r * 8;
-            vi = (q[2] * uint32_t(ys) + q[1]) * uint32_t(xs) + q[0];  // IDXS
-            vj = (q[6] * uint32_t(ys) + q[5]) * uint32_t(xs) + q[4];
+            if (requests) {
+                const uint32_t* q = requests + r * 8;
+                vi = (q[2] * uint32_t(ys) + q[1]) * uint32_t(xs) + q[0];  // IDXS
+                vj = (q[6] * uint32_t(ys) + q[5]) * uint32_t(xs) + q[4];
+            } else {
+                vi = vj = uint32_t(r);
+            }
         }
         bool is_nan = false;
         float mn = __uint_as_float(0x7F7FFFFFu), mx = __uint_as_float(0xFF7FFFFFu);
 #pragma unroll 4
         for (int e = 0; e < cs; e++) {
-            const float xv = load_member(members[e], vi * 4u);
-            const float yv = load_member(members[e], vj * 4u);
+            const float xv = load_member(members_i[e], vi * 4u);
+            const float yv = load_member(members_j[e], vj * 4u);
             is_nan |= (xv != xv) || (yv != yv);
             x[e * 64] = xv;
             y[e * 64] = yv;
@@ -495,10 +504,12 @@ __global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __
             case 3:
             case 5: {
                 int total = 0;
-                const float range = mx - mn;
+                const float mnx = a.fixed_ranges ? a.min_ref : mn, mny = a.fixed_ranges ? a.min_query : mn;
+                const float range_x = a.fixed_ranges ? a.max_ref - a.min_ref : mx - mn;
+                const float range_y = a.fixed_ranges ? a.max_query - a.min_query : mx - mn;
 #pragma unroll 2
                 for (int e = 0; e < cs; e++) {
-                    const float x01 = (x[e * 64] - mn) / range, y01 = (y[e * 64] - mn) / range;
+                    const float x01 = (x[e * 64] - mnx) / range_x, y01 = (y[e * 64] - mny) / range_y;
                     const bool valid = (x01 == x01) && (y01 == y01);
                     int b0 = int(double(x01) * double(num_bins)), b1 = int(double(y01) * double(num_bins));
                     b0 = b0 < 0 ? 0 : (b0 > num_bins - 1 ? num_bins - 1 : b0);
@@ -522,18 +533,17 @@ __global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __
     }
 }
 
-hipError_t launch_pair_requests(const float* const* d_members, int cs, int xs, int ys, size_t num_voxels,
-                                const uint32_t* d_requests, size_t num_requests, int measure, int num_bins, int k,
-                                bool use_abs, const double* d_tables, unsigned char* d_workspace, float* d_out,
-                                hipStream_t s) {
+hipError_t launch_pair_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
+                                size_t num_voxels, const uint32_t* d_requests, size_t num_requests, const PairArgs& a,
+                                const double* d_tables, unsigned char* d_workspace, float* d_out, hipStream_t s) {
     if (num_requests == 0) return hipSuccess;
     const size_t tiles = (num_requests + 63) / 64;
     const unsigned blocks = unsigned(tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
     const bool use_lds = pair_tile_bytes(cs) <= kLdsTileLimit;
     if (!use_lds && !d_workspace) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pair_request_kernel, dim3(blocks), dim3(64), use_lds ? pair_tile_bytes(cs) : 0, s, d_members,
-                       d_requests, d_tables, d_out, num_requests, num_voxels, xs, ys, cs, measure, num_bins, k,
-                       int(use_abs), use_lds ? nullptr : d_workspace);
+    hipLaunchKernelGGL(pair_request_kernel, dim3(blocks), dim3(64), use_lds ? pair_tile_bytes(cs) : 0, s, d_members_i,
+                       d_members_j, d_requests, d_tables, d_out, num_requests, num_voxels, xs, ys, cs, a,
+                       use_lds ? nullptr : d_workspace);
     return hipGetLastError();
 }
 

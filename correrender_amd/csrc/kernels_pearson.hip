@@ -183,6 +183,64 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Symmetric field mode (CorrelationFieldMode::SEPARATE_SYMMETRIC, CorrelationMain.glsl:10-15): voxel v correlates
+// the reference field's members at v with the query field's members at v -- computePearson2 on two arrays
+// (Correlation.cpp:141-174), nothing to hoist.  2*cs loads per voxel (8*cs + 4 algorithmic bytes), both sides in
+// registers.  Same guarded-slot scheme as pearson_reg_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int CS_PAD, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void pearson_symmetric_kernel(const float* const* __restrict__ members_x,
+                                                                           const float* const* __restrict__ members_y,
+                                                                           float* __restrict__ out,
+                                                                           uint32_t num_voxels, int cs) {
+    constexpr int kFirstGuarded = EXACT ? CS_PAD : CS_PAD - 16;
+    const auto is_member = [cs](int e) { return e < kFirstGuarded || e < cs; };
+    const uint32_t v0 = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t byte_offset = v0 * 4u;
+    const uint32_t bytes = num_voxels * 4u;
+    float x[CS_PAD], y[CS_PAD];
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        const int slot = (e < kFirstGuarded || e < cs) ? e : cs - 1;
+        const uint32_t off = is_member(e) ? byte_offset : kOutOfRangeOffset;
+        x[e] = load_member_nt(members_x[slot], bytes, off);
+        y[e] = load_member_nt(members_y[slot], bytes, off);
+    }
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanX = 0.0f, meanY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        meanX += invN * x[e];
+        meanY += invN * y[e];
+    }
+    float varX = 0.0f, varY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CS_PAD; e++) {
+        const float dx = is_member(e) ? x[e] - meanX : 0.0f;
+        const float dy = is_member(e) ? y[e] - meanY : 0.0f;
+        x[e] = dx;
+        y[e] = dy;
+        varX += invNm1 * dx * dx;
+        varY += invNm1 * dy * dy;
+    }
+    const float sdX = sqrtf(varX), sdY = sqrtf(varY);
+    float r = 0.0f;
+    if (__all(exact_div_guard(meanX, sdX) && exact_div_guard(meanY, sdY))) {
+        const float rcpX = 1.0f / sdX, rcpY = 1.0f / sdY;
+#pragma unroll
+        for (int e = 0; e < CS_PAD; e++)
+            r += (invNm1 * exact_div(x[e], sdX, rcpX)) * exact_div(y[e], sdY, rcpY);
+    } else {
+#pragma unroll
+        for (int e = 0; e < CS_PAD; e++)
+            r += (invNm1 * (is_member(e) ? x[e] / sdX : 0.0f)) * (is_member(e) ? y[e] / sdY : 0.0f);
+    }
+    if (v0 < num_voxels) out[v0] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Streaming fallback for any cs (three passes re-reading the members; the second and third mostly hit L2/MALL) and
 // for the ragged tail of the grid.  One voxel per lane, bounds-checked.
 // ---------------------------------------------------------------------------------------------------------
@@ -252,6 +310,38 @@ int env_int(const char* name, int fallback) {
 hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_out, n, value);
+    return hipGetLastError();
+}
+
+namespace {
+template <int CS_PAD>
+void launch_symmetric(const float* const* mx, const float* const* my, int cs, size_t num_voxels, float* d_out,
+                      hipStream_t s) {
+    constexpr int kMinWaves = CS_PAD <= 32 ? 4 : (CS_PAD <= 64 ? 2 : 1);
+    const unsigned blocks = unsigned((num_voxels + 255) / 256);
+    if (cs == CS_PAD)
+        hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, true, kMinWaves>), dim3(blocks), dim3(256), 0, s, mx, my,
+                           d_out, uint32_t(num_voxels), cs);
+    else
+        hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, false, kMinWaves>), dim3(blocks), dim3(256), 0, s, mx, my,
+                           d_out, uint32_t(num_voxels), cs);
+}
+}  // namespace
+
+hipError_t launch_pearson_symmetric(const float* const* d_members_ref, const float* const* d_members_query, int cs,
+                                    size_t num_voxels, float* d_out, hipStream_t s) {
+    if (cs == 1) return launch_fill(d_out, num_voxels, 1.0f, s);
+    if (cs > kMaxSymmetricRegisterMembers) return hipErrorNotSupported;
+    switch ((cs + 15) / 16) {
+        case 1: launch_symmetric<16>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 2: launch_symmetric<32>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 3: launch_symmetric<48>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 4: launch_symmetric<64>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 5: launch_symmetric<80>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 6: launch_symmetric<96>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        case 7: launch_symmetric<112>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+        default: launch_symmetric<128>(d_members_ref, d_members_query, cs, num_voxels, d_out, s); break;
+    }
     return hipGetLastError();
 }
 

@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import FLAG_ABSOLUTE_VALUE, CorrFieldError, CrfParams, load_library
+from ._lib import (FLAG_ABSOLUTE_VALUE, FLAG_REFERENCE_FROM_SECONDARY, FLAG_SYMMETRIC, CorrFieldError, CrfParams,
+                   load_library)
 
 
 class Measure(enum.IntEnum):
@@ -107,6 +108,28 @@ class CorrField:
         self._check(self._lib.crf_member_minmax(self._ctx, C.byref(mn), C.byref(mx)))
         return mn.value, mx.value
 
+    # -- secondary members: the second scalar field of the SEPARATE / SEPARATE_SYMMETRIC field modes ---------
+    def upload_secondary_members(self, members: Sequence[np.ndarray]):
+        arrs = [np.ascontiguousarray(m, dtype=np.float32) for m in members]
+        if len(arrs) != self.cs or any(a.size != self.num_voxels for a in arrs):
+            raise ValueError("secondary members do not match the grid declared with set_grid")
+        ptrs = (C.c_void_p * self.cs)(*[a.ctypes.data for a in arrs])
+        self._check(self._lib.crf_upload_secondary_members(self._ctx, ptrs))
+
+    def bind_secondary_members(self, members):
+        tensors = [members[i] for i in range(self.cs)]
+        for t in tensors:
+            if not t.is_cuda or not t.is_contiguous() or t.numel() != self.num_voxels or t.element_size() != 4:
+                raise ValueError("each member must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
+        ptrs = (C.c_void_p * self.cs)(*[t.data_ptr() for t in tensors])
+        self._check(self._lib.crf_bind_secondary_members_device(self._ctx, ptrs))
+        self._keepalive_secondary = (members, tensors)
+
+    def secondary_member_minmax(self):
+        mn, mx = C.c_float(), C.c_float()
+        self._check(self._lib.crf_secondary_member_minmax(self._ctx, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
     # -- reference vector ---------------------------------------------------------------------------------
     def gather_reference(self, x: int, y: int, z: int) -> np.ndarray:
         out = np.empty(self.cs, dtype=np.float32)
@@ -119,9 +142,10 @@ class CorrField:
 
     # -- evaluation ---------------------------------------------------------------------------------------
     def _params(self, measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
-                reference_values):
+                reference_values, flags=0):
         p = CrfParams()
         p.measure = int(measure)
+        p.flags = int(flags)
         rx, ry, rz = ref if ref is not None else (0, 0, 0)
         p.ref_x, p.ref_y, p.ref_z = int(rx), int(ry), int(rz)
         p.k = int(k if k is not None else default_kraskov_k(self.cs))
@@ -139,20 +163,42 @@ class CorrField:
             p.reference_values = keep.ctypes.data_as(C.POINTER(C.c_float))
         return p, keep
 
-    def _binned_ranges(self, measure, minmax_ref, minmax_query):
+    def _binned_ranges(self, measure, minmax_ref, minmax_query, mode="single"):
         if int(measure) in (Measure.MUTUAL_INFORMATION_BINNED, Measure.BINNED_MI_CORRELATION_COEFFICIENT):
-            if minmax_ref is None:
-                minmax_ref = self.member_minmax()      # SINGLE mode: CorrelationCalculator.cpp:822-829
-            if minmax_query is None:
-                minmax_query = minmax_ref              # :843-846
+            if mode == "single":
+                if minmax_ref is None:
+                    minmax_ref = self.member_minmax()      # SINGLE mode: CorrelationCalculator.cpp:822-829
+                if minmax_query is None:
+                    minmax_query = minmax_ref              # :843-846
+            elif mode == "separate":                       # reference field = secondary, query = primary (:820-842)
+                if minmax_ref is None:
+                    minmax_ref = self.secondary_member_minmax()
+                if minmax_query is None:
+                    minmax_query = self.member_minmax()
+            else:                                          # symmetric: reference = primary, query = secondary
+                if minmax_ref is None:
+                    minmax_ref = self.member_minmax()
+                if minmax_query is None:
+                    minmax_query = self.secondary_member_minmax()
         return minmax_ref, minmax_query
 
+    @staticmethod
+    def _mode_flags(symmetric, reference_from_secondary):
+        if symmetric:
+            return FLAG_SYMMETRIC, "symmetric"
+        if reference_from_secondary:
+            return FLAG_REFERENCE_FROM_SECONDARY, "separate"
+        return 0, "single"
+
     def compute(self, measure, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
-                minmax_query=None, reference_values=None) -> np.ndarray:
-        """Synchronous evaluation to a host array of shape (zs, ys, xs) -- calculateCpu(t, e, buffer)."""
-        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query)
+                minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False) -> np.ndarray:
+        """Synchronous evaluation to a host array of shape (zs, ys, xs) -- calculateCpu(t, e, buffer).
+        symmetric: SEPARATE_SYMMETRIC field mode (primary vs secondary members at every voxel);
+        reference_from_secondary: SEPARATE field mode (reference vector = secondary members at `ref`)."""
+        flags, mode = self._mode_flags(symmetric, reference_from_secondary)
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
-                               reference_values)
+                               reference_values, flags)
         xs, ys, zs = self.grid
         out = np.empty((zs, ys, xs), dtype=np.float32)
         self._check(self._lib.crf_compute(self._ctx, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))))
@@ -161,11 +207,12 @@ class CorrField:
 
     def compute_device(self, measure, out, ref=None, *, device_reference=None, stream: int = 0, k=None,
                        kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
-                       reference_values=None):
+                       reference_values=None, symmetric=False, reference_from_secondary=False):
         """Asynchronous, stream-ordered evaluation into a CUDA float32 tensor `out` of xs*ys*zs elements."""
-        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query)
+        flags, mode = self._mode_flags(symmetric, reference_from_secondary)
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
-                               reference_values)
+                               reference_values, flags)
         if out.numel() != self.num_voxels or not out.is_cuda or not out.is_contiguous():
             raise ValueError("out must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
         dref = C.c_void_p(device_reference.data_ptr()) if device_reference is not None else C.c_void_p(0)

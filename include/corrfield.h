@@ -68,13 +68,27 @@ typedef struct crf_params {
     const float* reference_values;   /* HOST pointer to cs floats, or NULL.  Non-NULL = CorrelationFieldMode::SEPARATE
                                         / time-lag (reference vector taken from another field, :804-813) or a vector
                                         received from another rank. */
-    int32_t flags;                   /* CRF_FLAG_*; only read by the pair-request entry points */
+    int32_t flags;                   /* CRF_FLAG_* */
     int32_t reserved[3];             /* must be 0 */
 } crf_params;
 
 /* useAbsoluteCorrelationMeasure of the pair-request path (HEBChartCorrelation.cpp:583-585).  The full-grid path ignores
  * calculate_absolute_value on the CPU exactly like the reference (CorrelationCalculator.cpp:1662-1664). */
 #define CRF_FLAG_ABSOLUTE_VALUE 1
+/* CorrelationFieldMode::SEPARATE_SYMMETRIC (CorrelationCalculator.hpp:59-64): crf_compute[_device] evaluate, at every
+ * voxel v, the measure between X[c] = member_c[v] (the reference field = the primary members) and Y[c] =
+ * secondary_member_c[v] (the query field) -- `#define referencePointIdx currentPointIdx`, CorrelationMain.glsl:10-15;
+ * scalarFieldsRef = scalarFields, scalarFieldsQuery = scalarFieldsSecondary, ScalarFields.glsl:107-117.  The
+ * reference implements this mode on its Vulkan path only (CorrelationCalculator.cpp:1182-1229; calculateCpu falls into
+ * the SINGLE branch), so the arithmetic here is DEFINED as calculateCpu's per-voxel computation with the reference
+ * vector taken from the primary field at the same voxel; a NaN in either vector gives NaN; Kraskov is KSG-1 (the
+ * shaders ignore the estimator index).  Binned MI normalises X with min_ref/max_ref and Y with min_query/max_query.
+ * The reference point / reference_values are not read. */
+#define CRF_FLAG_SYMMETRIC 2
+/* CorrelationFieldMode::SEPARATE on the device: the reference vector is gathered from the SECONDARY members at
+ * (ref_x, ref_y, ref_z) -- referenceValues[c] = field2_c[IDXS(ref)], CorrelationCalculator.cpp:804-813 (for time-lag
+ * correlations bind the secondary field's members of the lagged time step). */
+#define CRF_FLAG_REFERENCE_FROM_SECONDARY 4
 
 /* One pair request: the estimator between the ensemble vectors of voxel (xi,yi,zi) and voxel (xj,yj,zj).  Same layout
  * as struct CorrelationRequestData {xi,yi,zi,i,xj,yj,zj,j} (src/Renderers/Diagram/HEBChart.hpp:166-168,
@@ -105,6 +119,12 @@ int crf_bind_members_device(crf_context* ctx, const void* const* device_members)
  * top of VolumeData::getMinMaxScalarFieldValue, VolumeData.cpp:1632-1670); computed on the device, cached until
  * the members change. */
 int crf_member_minmax(crf_context* ctx, float* out_min, float* out_max);
+/* The second scalar field of the SEPARATE / SEPARATE_SYMMETRIC field modes (fieldIndex2Gui; fieldEntriesSecondary,
+ * CorrelationCalculator.cpp:1182-1229): cs volumes of the same local grid, uploaded or borrowed like the primary
+ * members; dropped by crf_set_grid.  Used by CRF_FLAG_SYMMETRIC / CRF_FLAG_REFERENCE_FROM_SECONDARY. */
+int crf_upload_secondary_members(crf_context* ctx, const float* const* host_members);
+int crf_bind_secondary_members_device(crf_context* ctx, const void* const* device_members);
+int crf_secondary_member_minmax(crf_context* ctx, float* out_min, float* out_max);
 
 /* ---- reference vector (CorrelationCalculator.cpp:802,815-817) --------------------------------------------- */
 /* referenceValues[c] = member_c[IDXS(x,y,z)] -> cs floats to a host buffer (synchronous) ... */

@@ -568,6 +568,47 @@ int oracle_pair_requests(int measure, const float* const* fields, int cs, const 
 }
 
 /*
+ * CorrelationFieldMode::SEPARATE_SYMMETRIC.  PARITY UNPINNED BY THE REFERENCE'S CPU CODE: calculateCpu has no branch for
+ * this mode (it falls into SINGLE, CorrelationCalculator.cpp:802-818); only the Vulkan path implements it
+ * (CorrelationCalculator.cpp:1182-1229, `#define referencePointIdx currentPointIdx` CorrelationMain.glsl:10-15), with
+ * the fp32 shader arithmetic that matches no CPU result (SURVEY 8a "GPU != CPU notes").  The engine therefore DEFINES
+ * the mode as calculateCpu's own per-voxel computation with the reference vector taken from the reference field at
+ * the same voxel -- which is what this function evaluates, literally, by calling oracle_correlation_field on the
+ * one-voxel range [v, v+1) with refValues[c] = fieldsRef[c][v].  A NaN in the reference vector gives NaN (the query
+ * side already does, :929-940); Kraskov is KSG-1 (the shaders ignore the estimator index).
+ */
+int oracle_symmetric_field(int measure, const float* const* fieldsRef, const float* const* fieldsQuery, int cs,
+                           size_t voxelBegin, size_t voxelEnd, int k, int numBins, float minRef, float maxRef,
+                           float minQuery, float maxQuery, float* out) {
+    if (cs < 1 || voxelEnd < voxelBegin) return 1;
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    int status = 0;
+#pragma omp parallel
+    {
+        std::vector<float> ref((size_t)cs);
+#pragma omp for schedule(static)
+        for (long long i = 0; i < (long long)(voxelEnd - voxelBegin); i++) {
+            const size_t v = voxelBegin + size_t(i);
+            bool isNan = false;
+            for (int c = 0; c < cs; c++) {
+                ref[size_t(c)] = fieldsRef[c][v];
+                isNan = isNan || std::isnan(ref[size_t(c)]);
+            }
+            if (isNan && cs > 1) {
+                out[i] = qnan;
+                continue;
+            }
+            if (oracle_correlation_field(measure, fieldsQuery, cs, v, v + 1, ref.data(), k, 1, numBins, minRef, maxRef,
+                                         minQuery, maxQuery, out + i, 1) != 0) {
+#pragma omp atomic write
+                status = 1;
+            }
+        }
+    }
+    return status;
+}
+
+/*
  * Ensemble mean (kind 0) / spread (kind 1): EnsembleMeanCalculator.cpp:110-134, EnsembleSpreadCalculator.cpp:110-145.
  * (Those translation units need sgl/VolumeData and cannot be compiled here; plain fp32 loops, restated.)
  */

@@ -46,6 +46,10 @@ class Oracle:
         lib.oracle_correlation_field.argtypes = [
             C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, FP, C.c_int, C.c_int, C.c_int,
             C.c_float, C.c_float, C.c_float, C.c_float, FP, C.c_int]
+        lib.oracle_symmetric_field.restype = C.c_int
+        lib.oracle_symmetric_field.argtypes = [
+            C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+            C.c_float, C.c_float, C.c_float, C.c_float, FP]
         lib.oracle_max_threads.restype = C.c_int
         lib.oracle_ensemble_stat.restype = C.c_int
         lib.oracle_ensemble_stat.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, FP]
@@ -111,6 +115,22 @@ class Oracle:
             int(measure), ptrs, cs, lo, hi, _fp(ref_values), int(k), int(estimator), int(num_bins),
             float(minmax_ref[0]), float(minmax_ref[1]), float(minmax_query[0]), float(minmax_query[1]), _fp(out),
             int(threads))
+        assert rc == 0
+        return out
+
+    def symmetric_field(self, measure, members_ref, members_query, *, k=3, num_bins=80, minmax_ref=(0.0, 1.0),
+                        minmax_query=(0.0, 1.0), voxel_range=None):
+        """SEPARATE_SYMMETRIC: measure(members_ref[:, v], members_query[:, v]) at every voxel v."""
+        mr, mq = _members(members_ref), _members(members_query)
+        cs = len(mr)
+        assert len(mq) == cs
+        lo, hi = voxel_range if voxel_range is not None else (0, mr[0].size)
+        pr = (C.c_void_p * cs)(*[m.ctypes.data for m in mr])
+        pq = (C.c_void_p * cs)(*[m.ctypes.data for m in mq])
+        out = np.empty(hi - lo, np.float32)
+        rc = self.lib.oracle_symmetric_field(int(measure), pr, pq, cs, lo, hi, int(k), int(num_bins),
+                                             float(minmax_ref[0]), float(minmax_ref[1]), float(minmax_query[0]),
+                                             float(minmax_query[1]), _fp(out))
         assert rc == 0
         return out
 

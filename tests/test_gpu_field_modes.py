@@ -1,0 +1,120 @@
+"""GPU parity: the two-field modes of the correlation calculator.
+
+SEPARATE (CorrelationCalculator.cpp:804-813): the reference vector comes from the SECOND field at the reference point,
+the per-voxel vectors from the first -- calculateCpu's own arithmetic, so the oracle's field driver with that vector is
+the expectation (bit-exact for Pearson / Spearman / Kendall).
+
+SEPARATE_SYMMETRIC (CorrelationMain.glsl:10-15, Vulkan path only in the reference): first field vs second field at the
+same voxel.  The expectation is oracle_symmetric_field = calculateCpu's per-voxel computation with the reference vector
+following the voxel (parity unpinned by the reference's CPU code: see the oracle's header comment)."""
+import numpy as np
+import pytest
+
+from correrender_amd import CorrFieldError, Measure
+from parity import assert_bit_exact, assert_close, bit_identical
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+EXACT = [(Measure.PEARSON, 0), (Measure.SPEARMAN, 1), (Measure.KENDALL, 2)]
+FLOATING = [(Measure.MUTUAL_INFORMATION_BINNED, 3), (Measure.MUTUAL_INFORMATION_KRASKOV, 4),
+            (Measure.BINNED_MI_CORRELATION_COEFFICIENT, 5), (Measure.KMI_CORRELATION_COEFFICIENT, 6)]
+
+
+def _two_fields(cs, shape=(4, 6, 16), seed=0, rho=0.6):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((cs,) + shape).astype(np.float32)
+    b = (rho * a + np.sqrt(1 - rho * rho) * rng.standard_normal((cs,) + shape)).astype(np.float32)
+    b[:, 0, 0, :] = a[:, 0, 0, :]                   # identical vectors: correlation exactly 1
+    b[:, 0, 1, :] = -2.0 * a[:, 0, 1, :]            # exactly anti-correlated
+    return a, b
+
+
+def _setup(engine, a, b):
+    cs, zs, ys, xs = a.shape
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(a)
+    engine.upload_secondary_members(b)
+
+
+@pytest.mark.parametrize("measure,omeasure", EXACT)
+@pytest.mark.parametrize("cs", [2, 7, 16, 24, 40, 64, 100, 128, 150])
+def test_symmetric_exact_measures(engine, oracle, measure, omeasure, cs):
+    a, b = _two_fields(cs, seed=cs)
+    a[1, 2, 3, 4] = np.nan                          # NaN on the reference side
+    b[0, 3, 1, 2] = np.nan                          # NaN on the query side
+    b[:, 1, 1, 1] = 2.5                             # constant query vector
+    a[:, 1, 2, 1] = np.round(a[:, 1, 2, 1])         # ties
+    _setup(engine, a, b)
+    got = engine.compute(measure, symmetric=True)
+    want = oracle.symmetric_field(omeasure, a, b)
+    assert_bit_exact(got, want, f"symmetric {measure.name} cs={cs}")
+    g = got.reshape(a.shape[1:])
+    assert np.isnan(g[2, 3, 4]) and np.isnan(g[3, 1, 2])
+    if measure == Measure.PEARSON and cs >= 7:
+        assert g[0, 0, 5] == pytest.approx(1.0, abs=1e-5) and g[0, 1, 5] == pytest.approx(-1.0, abs=1e-5)
+
+
+@pytest.mark.parametrize("measure,omeasure", FLOATING)
+@pytest.mark.parametrize("cs", [16, 50, 64])
+def test_symmetric_mutual_information(engine, oracle, measure, omeasure, cs):
+    a, b = _two_fields(cs, seed=100 + cs)
+    b *= 3.0                                        # different value ranges: the two normalisations differ
+    _setup(engine, a, b)
+    mm_a, mm_b = engine.member_minmax(), engine.secondary_member_minmax()
+    assert mm_a == oracle.minmax(a) and mm_b == oracle.minmax(b)
+    got = engine.compute(measure, symmetric=True, k=3, num_bins=20)
+    want = oracle.symmetric_field(omeasure, a, b, k=3, num_bins=20, minmax_ref=mm_a, minmax_query=mm_b)
+    assert_close(got, want, f"symmetric {measure.name} cs={cs}")
+    assert bit_identical(got, want).mean() > 0.99
+
+
+@pytest.mark.parametrize("measure,omeasure", EXACT + FLOATING[:2])
+def test_separate_reference_from_second_field(engine, oracle, measure, omeasure):
+    a, b = _two_fields(32, seed=5)
+    _setup(engine, a, b)
+    ref = (3, 2, 1)
+    ref_values = b[:, ref[2], ref[1], ref[0]].copy()
+    kw, okw = {}, {}
+    if omeasure == 3:
+        kw = dict(num_bins=24)
+        okw = dict(num_bins=24, minmax_ref=oracle.minmax(b), minmax_query=oracle.minmax(a))
+    if omeasure == 4:
+        kw = okw = dict(k=2)
+    got = engine.compute(measure, ref, reference_from_secondary=True, **kw)
+    want = oracle.field(omeasure, a, ref_values, **okw)
+    if omeasure <= 2:
+        assert_bit_exact(got, want, f"separate {measure.name}")
+    else:
+        assert_close(got, want, f"separate {measure.name}")
+    # the same through an explicit host vector (the form the reference's calculateCpu uses, :804-813)
+    got2 = engine.compute(measure, reference_values=ref_values,
+                          **({**kw, "minmax_ref": okw["minmax_ref"], "minmax_query": okw["minmax_query"]}
+                             if omeasure == 3 else kw))
+    assert bit_identical(got, got2).all()
+
+
+def test_symmetric_device_output_and_large_grid(engine, oracle):
+    import torch
+    cs, xs, ys, zs = 64, 64, 64, 16
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((cs, zs, ys, xs)).astype(np.float32)
+    b = (0.3 * a + rng.standard_normal((cs, zs, ys, xs))).astype(np.float32)
+    engine.set_grid(xs, ys, zs, cs)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    engine.bind_members(ta)
+    engine.bind_secondary_members(tb)
+    out = torch.empty(xs * ys * zs, dtype=torch.float32, device="cuda")
+    engine.compute_device(Measure.PEARSON, out, symmetric=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = oracle.symmetric_field(0, a, b)
+    assert_bit_exact(out.cpu().numpy(), want, "symmetric Pearson 64x64x16x64, device buffers")
+
+
+def test_two_field_modes_need_secondary_members(engine):
+    engine.set_grid(4, 4, 2, 8)
+    engine.upload_members(np.zeros((8, 2, 4, 4), np.float32))
+    with pytest.raises(CorrFieldError, match="secondary"):
+        engine.compute(Measure.PEARSON, symmetric=True)
+    with pytest.raises(CorrFieldError, match="secondary"):
+        engine.compute(Measure.PEARSON, (0, 0, 0), reference_from_secondary=True)

@@ -64,6 +64,11 @@ def test_calculate_cpu_ensemble_mode(tmp_path, oracle):
                                                       minmax_ref=oracle.minmax(ens2), minmax_query=mm), "separate binned")
     ref_lag = data[1, 0][:, 3, 2, 1].copy()                                      # time-lag: field 2 at time step 0
     assert_bit_exact(out("pearson_separate_lag0"), oracle.field(oracle_lib.PEARSON, ens, ref_lag), "time lag")
+    # SEPARATE_SYMMETRIC: field 1 (reference side) vs field 2 (query side) at every voxel
+    assert_bit_exact(out("kendall_symmetric"), oracle.symmetric_field(oracle_lib.KENDALL, ens, ens2), "symmetric kendall")
+    assert_close(out("binned_symmetric"), oracle.symmetric_field(oracle_lib.MI_BINNED, ens, ens2, num_bins=80,
+                                                                 minmax_ref=mm, minmax_query=oracle.minmax(ens2)),
+                 "symmetric binned")
 
 
 @pytest.mark.gpu

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--members", type=int, nargs="*", default=[8, 12, 16, 24, 32, 40, 48, 64, 96, 100, 128])
     ap.add_argument("--measures", nargs="*", default=["pearson", "spearman", "kendall", "mi_binned", "mi_kraskov"])
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--symmetric", action="store_true", help="SEPARATE_SYMMETRIC field mode (two ensembles)")
     args = ap.parse_args()
     xs, ys, zs = args.grid
     n = xs * ys * zs
@@ -32,15 +33,23 @@ def main():
             eng.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, 1234, stream)
         torch.cuda.synchronize()
         eng.bind_members(members)
+        if args.symmetric:
+            block2 = torch.empty(cs * n, dtype=torch.float32, device="cuda")
+            members2 = [block2[c * n:(c + 1) * n] for c in range(cs)]
+            for c in range(cs):
+                eng.synth_box_member(members2[c], xs, ys, zs, 0, zs, c, cs, 4321, stream)
+            torch.cuda.synchronize()
+            eng.bind_secondary_members(members2)
         eng.set_profiling(True)
         row = []
         for name in args.measures:
             measure = ca.Measure(ca.MEASURE_IDS.index(name))
             iters = 2 if name == "mi_kraskov" else args.iters
-            kw = dict(k=ca.default_kraskov_k(cs))
+            kw = dict(k=ca.default_kraskov_k(cs), symmetric=args.symmetric)
             if name == "mi_binned":
                 mm = eng.member_minmax()
-                kw.update(minmax_ref=mm, minmax_query=mm, num_bins=80)
+                kw.update(minmax_ref=mm, minmax_query=eng.secondary_member_minmax() if args.symmetric else mm,
+                          num_bins=80)
             eng.compute_device(measure, out, (1, 2, 3), stream=stream, **kw)
             torch.cuda.synchronize()
             eng.take_kernel_time()
