@@ -695,6 +695,58 @@ int crf_compute_ensemble_stat(crf_context* c, int stat, float* host_out) {
     return CRF_OK;
 }
 
+int crf_compute_set_predicate_device(crf_context* c, int op, float comparison_value, int count_lower, int count_upper,
+                                     void* device_out, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!device_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (op < CRF_CMP_GREATER || op > CRF_CMP_NOT_EQUAL)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("unknown comparison operator %d", op));
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = take_event(c);
+        e1 = take_event(c);
+    }
+    crf::LaunchInfo info;
+    hipError_t e = crf::launch_set_predicate(c->d_member_table, c->cs, c->num_voxels, op, comparison_value, count_lower,
+                                             count_upper, static_cast<float*>(device_out), s, e0, e1, &info);
+    c->last_kernel = info.kernel_name ? info.kernel_name : "";
+    if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
+int crf_compute_set_predicate(crf_context* c, int op, float comparison_value, int count_lower, int count_upper,
+                              float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (int r = bind_device(c)) return r;
+    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
+    if (int r = crf_compute_set_predicate_device(c, op, comparison_value, count_lower, count_upper, c->d_out, nullptr))
+        return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_out, c->num_voxels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
+size_t crf_tiled_element_count(int xs, int ys, int zs) {
+    if (xs <= 0 || ys <= 0 || zs <= 0) return 0;
+    return size_t((xs + 7) / 8) * size_t((ys + 7) / 8) * size_t((zs + 3) / 4) * 256;
+}
+
+int crf_tile_field_device(crf_context* c, const void* device_linear, void* device_tiled, void* stream) {
+    if (!c) return CRF_ERR_ARGUMENT;
+    if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    if (!device_linear || !device_tiled) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    hipError_t e = crf::launch_tile_field(static_cast<const float*>(device_linear), static_cast<float*>(device_tiled),
+                                          c->xs, c->ys, c->zs, s);
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
 int crf_set_profiling(crf_context* c, int enabled) {
     if (!c) return CRF_ERR_ARGUMENT;
     c->profiling = enabled != 0;

@@ -96,6 +96,11 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
 hipError_t launch_ensemble_stat(int kind, const float* const* d_members, int cs, size_t num_voxels, float* d_out,
                                 hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
+hipError_t launch_set_predicate(const float* const* d_members, int cs, size_t num_voxels, int op, float comparison_value,
+                                int count_lower, int count_upper, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                                hipEvent_t ev_end, LaunchInfo* info);
+hipError_t launch_tile_field(const float* d_linear, float* d_tiled, int xs, int ys, int zs, hipStream_t s);
+
 // pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}; voxel i is read from
 // d_members_i, voxel j from d_members_j.  d_requests == nullptr: request r = voxel pair (r, r) (symmetric field mode).
 struct PairArgs {

@@ -251,6 +251,36 @@ class CorrField:
                                                                C.c_void_p(stream)))
         return out
 
+    COMPARISON_OPERATORS = (">", ">=", "<", "<=", "==", "!=")   # COMPARISON_OPERATOR_NAMES, SetPredicateCalculator.hpp:44-46
+
+    def set_predicate(self, op, comparison_value: float, count_lower: int, count_upper: int) -> np.ndarray:
+        """SetPredicateCalculator::calculateCpu: fraction-of-members predicate field; `op` is an operator string or
+        its ComparisonOperatorType index; shape (zs, ys, xs)."""
+        op = self.COMPARISON_OPERATORS.index(op) if isinstance(op, str) else int(op)
+        xs, ys, zs = self.grid
+        out = np.empty((zs, ys, xs), dtype=np.float32)
+        self._check(self._lib.crf_compute_set_predicate(self._ctx, op, C.c_float(comparison_value), int(count_lower),
+                                                        int(count_upper), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_predicate_device(self, op, comparison_value, count_lower, count_upper, out, stream: int = 0):
+        op = self.COMPARISON_OPERATORS.index(op) if isinstance(op, str) else int(op)
+        self._check(self._lib.crf_compute_set_predicate_device(
+            self._ctx, op, C.c_float(comparison_value), int(count_lower), int(count_upper), C.c_void_p(out.data_ptr()),
+            C.c_void_p(stream)))
+        return out
+
+    def tiled_element_count(self) -> int:
+        return int(self._lib.crf_tiled_element_count(*self.grid))
+
+    def tile_field_device(self, linear, tiled, stream: int = 0):
+        """Linear (IDXS) CUDA field -> the reference's 8x8x4-tiled device layout (VolumeData.cpp:1581-1621)."""
+        if linear.numel() != self.num_voxels or tiled.numel() != self.tiled_element_count():
+            raise ValueError("tile_field_device: buffer sizes do not match the grid")
+        self._check(self._lib.crf_tile_field_device(self._ctx, C.c_void_p(linear.data_ptr()),
+                                                    C.c_void_p(tiled.data_ptr()), C.c_void_p(stream)))
+        return tiled
+
     # -- instrumentation ----------------------------------------------------------------------------------
     def set_profiling(self, enabled: bool):
         self._check(self._lib.crf_set_profiling(self._ctx, 1 if enabled else 0))

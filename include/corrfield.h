@@ -162,6 +162,27 @@ typedef enum crf_ensemble_stat {
 int crf_compute_ensemble_stat(crf_context* ctx, int stat, float* host_out);
 int crf_compute_ensemble_stat_device(crf_context* ctx, int stat, void* device_out, void* stream);
 
+/* SetPredicateCalculator::calculateCpu (src/Calculators/SetPredicateCalculator.cpp:154-210): count = number of members
+ * with `value OP comparison_value`; out = clamp(count - count_lower, 0, 1) when count_lower == count_upper, else
+ * clamp((count - count_lower) / (count_upper - count_lower), 0, 1), all in fp32.  Operator values follow
+ * ComparisonOperatorType (SetPredicateCalculator.hpp:41-43); NaN compares as in C. */
+typedef enum crf_comparison_operator {
+    CRF_CMP_GREATER = 0, CRF_CMP_GREATER_EQUAL = 1, CRF_CMP_LESS = 2, CRF_CMP_LESS_EQUAL = 3, CRF_CMP_EQUAL = 4,
+    CRF_CMP_NOT_EQUAL = 5
+} crf_comparison_operator;
+int crf_compute_set_predicate(crf_context* ctx, int comparison_operator, float comparison_value, int count_lower,
+                              int count_upper, float* host_out);
+int crf_compute_set_predicate_device(crf_context* ctx, int comparison_operator, float comparison_value, int count_lower,
+                                     int count_upper, void* device_out, void* stream);
+
+/* ---- result layout for the renderer -------------------------------------------------------------------------------- */
+/* The reference keeps device fields in 8x8x4 tiles (bufferTileSize, VolumeData.cpp:1581-1621; addressed by IDXS of
+ * Data/Shaders/Correlation/ScalarFields.glsl:32-50): tiles in x-fastest order, x-fastest inside a tile, grid padded up
+ * to whole tiles with zeros.  crf_tiled_element_count = ceil(xs/8)*ceil(ys/8)*ceil(zs/4)*256 floats;
+ * crf_tile_field_device re-lays a linear (IDXS) device field of the context's grid into that layout, stream-ordered. */
+size_t crf_tiled_element_count(int xs, int ys, int zs);
+int crf_tile_field_device(crf_context* ctx, const void* device_linear, void* device_tiled, void* stream);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* When enabled, every crf_compute* brackets its dominant (per-voxel) kernel with HIP events on the launch stream. */
 int crf_set_profiling(crf_context* ctx, int enabled);

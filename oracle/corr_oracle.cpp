@@ -652,4 +652,55 @@ int oracle_max_threads(void) {
 #endif
 }
 
+/*
+ * SetPredicateCalculator::calculateCpu (SetPredicateCalculator.cpp:171-206): op follows ComparisonOperatorType
+ * (SetPredicateCalculator.hpp:41-43: > >= < <= == !=).
+ */
+int oracle_set_predicate(int op, float comparisonValue, int countLower, int countUpper, const float* const* fields,
+                         int cs, size_t numPoints, float* out) {
+    if (op < 0 || op > 5) return 1;
+#pragma omp parallel for schedule(static)
+    for (long long p = 0; p < (long long)numPoints; p++) {
+        int count = 0;
+        for (int c = 0; c < cs; c++) {
+            const float v = fields[c][p];
+            bool hit = false;
+            switch (op) {
+                case 0: hit = v > comparisonValue; break;
+                case 1: hit = v >= comparisonValue; break;
+                case 2: hit = v < comparisonValue; break;
+                case 3: hit = v <= comparisonValue; break;
+                case 4: hit = v == comparisonValue; break;
+                default: hit = v != comparisonValue; break;
+            }
+            if (hit) count++;
+        }
+        if (countLower == countUpper) {
+            out[p] = std::clamp(float(count) - float(countLower), 0.0f, 1.0f);
+        } else {
+            out[p] = std::clamp((float(count) - float(countLower)) / (float(countUpper) - float(countLower)), 0.0f, 1.0f);
+        }
+    }
+    return 0;
+}
+
+/*
+ * Linear (IDXS) -> 8x8x4-tiled buffer layout (VolumeData.cpp:1581-1621): tiled must hold
+ * ceil(xs/8)*ceil(ys/8)*ceil(zs/4)*256 floats.
+ */
+void oracle_tile_field(const float* linear, int xs, int ys, int zs, float* tiled) {
+    const uint32_t tx = 8, ty = 8, tz = 4, tileNumVoxels = tx * ty * tz;
+    const uint32_t xst = (uint32_t(xs) + tx - 1) / tx, yst = (uint32_t(ys) + ty - 1) / ty, zst = (uint32_t(zs) + tz - 1) / tz;
+    for (uint32_t tileIdx = 0; tileIdx < xst * yst * zst; tileIdx++) {
+        const uint32_t xt = tileIdx % xst, yt = (tileIdx / xst) % yst, zt = tileIdx / (xst * yst);
+        for (uint32_t voxelIdx = 0; voxelIdx < tileNumVoxels; voxelIdx++) {
+            const uint32_t x = voxelIdx % tx + xt * tx, y = (voxelIdx / tx) % ty + yt * ty, z = voxelIdx / (tx * ty) + zt * tz;
+            float value = 0.0f;
+            if (x < uint32_t(xs) && y < uint32_t(ys) && z < uint32_t(zs))
+                value = linear[(size_t(z) * size_t(ys) + y) * size_t(xs) + x];
+            tiled[size_t(tileIdx) * tileNumVoxels + voxelIdx] = value;
+        }
+    }
+}
+
 }  // extern "C"

@@ -50,6 +50,11 @@ class Oracle:
         lib.oracle_symmetric_field.argtypes = [
             C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
             C.c_float, C.c_float, C.c_float, C.c_float, FP]
+        lib.oracle_set_predicate.restype = C.c_int
+        lib.oracle_set_predicate.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                             C.c_size_t, FP]
+        lib.oracle_tile_field.restype = None
+        lib.oracle_tile_field.argtypes = [FP, C.c_int, C.c_int, C.c_int, FP]
         lib.oracle_max_threads.restype = C.c_int
         lib.oracle_ensemble_stat.restype = C.c_int
         lib.oracle_ensemble_stat.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, FP]
@@ -132,6 +137,21 @@ class Oracle:
                                              float(minmax_ref[0]), float(minmax_ref[1]), float(minmax_query[0]),
                                              float(minmax_query[1]), _fp(out))
         assert rc == 0
+        return out
+
+    def set_predicate(self, op, comparison_value, count_lower, count_upper, members):
+        members = _members(members)
+        ptrs = (C.c_void_p * len(members))(*[m.ctypes.data for m in members])
+        out = np.empty(members[0].size, np.float32)
+        assert self.lib.oracle_set_predicate(int(op), float(comparison_value), int(count_lower), int(count_upper), ptrs,
+                                             len(members), members[0].size, _fp(out)) == 0
+        return out
+
+    def tile_field(self, linear):
+        zs, ys, xs = linear.shape
+        lin = _f32(linear)
+        out = np.empty(((xs + 7) // 8) * ((ys + 7) // 8) * ((zs + 3) // 4) * 256, np.float32)
+        self.lib.oracle_tile_field(_fp(lin), xs, ys, zs, _fp(out))
         return out
 
     def max_threads(self):

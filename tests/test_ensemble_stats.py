@@ -43,3 +43,62 @@ def test_gpu_ensemble_stats(engine, oracle, cs):
     engine.upload_members(ens)
     for kind in (0, 1):
         assert_bit_exact(engine.ensemble_stat(kind), oracle.ensemble_stat(kind, ens), f"ensemble stat {kind} cs={cs}")
+
+
+# ---- set predicate (SetPredicateCalculator) and the tiled result layout ---------------------------------------------
+OPS = [">", ">=", "<", "<=", "==", "!="]
+
+
+@pytest.mark.parametrize("op", range(6))
+def test_oracle_set_predicate_vs_numpy(oracle, op):
+    ens = _data(20, 77)
+    ens[:, 1, 1, 1] = 0.25
+    flat = ens.reshape(20, -1)
+    with np.errstate(invalid="ignore"):
+        hits = [flat > 0.25, flat >= 0.25, flat < 0.25, flat <= 0.25, flat == 0.25, flat != 0.25][op].sum(axis=0)
+    for lower, upper in [(10, 10), (5, 15), (0, 20), (12, 3)]:
+        want = (np.clip(hits.astype(np.float32) - np.float32(lower), 0, 1) if lower == upper else
+                np.clip((hits.astype(np.float32) - np.float32(lower)) / (np.float32(upper) - np.float32(lower)), 0, 1))
+        got = oracle.set_predicate(op, 0.25, lower, upper, ens)
+        np.testing.assert_array_equal(got, want.astype(np.float32))
+
+
+def test_oracle_tile_field_layout(oracle):
+    zs, ys, xs = 6, 10, 19                         # none a multiple of the tile size: padding on every axis
+    lin = np.arange(zs * ys * xs, dtype=np.float32).reshape(zs, ys, xs) + 1.0
+    tiled = oracle.tile_field(lin)
+    xst, yst, zst = 3, 2, 2
+    assert tiled.size == xst * yst * zst * 256
+    t = tiled.reshape(zst, yst, xst, 4, 8, 8)      # [zt, yt, xt, vz, vy, vx]
+    full = np.zeros((zst * 4, yst * 8, xst * 8), np.float32)
+    full[:zs, :ys, :xs] = lin
+    want = full.reshape(zst, 4, yst, 8, xst, 8).transpose(0, 2, 4, 1, 3, 5)
+    np.testing.assert_array_equal(t, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cs", [1, 7, 64, 100, 300])
+def test_gpu_set_predicate(engine, oracle, cs):
+    ens = _data(cs, 50 + cs)
+    ens[:, 1, 1, 1] = 0.25
+    _, zs, ys, xs = ens.shape
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    for op in range(6):
+        for lower, upper in [(cs // 2, cs // 2), (cs // 4, cs), (cs, 0)]:
+            got = engine.set_predicate(OPS[op], 0.25, lower, upper)
+            assert_bit_exact(got, oracle.set_predicate(op, 0.25, lower, upper, ens), f"set predicate {OPS[op]} cs={cs}")
+
+
+@pytest.mark.gpu
+def test_gpu_tile_field(engine, oracle):
+    import torch
+    zs, ys, xs = 6, 10, 19
+    lin = np.random.default_rng(1).standard_normal((zs, ys, xs)).astype(np.float32)
+    engine.set_grid(xs, ys, zs, 2)
+    assert engine.tiled_element_count() == 3 * 2 * 2 * 256
+    d_lin = torch.from_numpy(lin).cuda()
+    d_tiled = torch.full((engine.tiled_element_count(),), -1.0, dtype=torch.float32, device="cuda")
+    engine.tile_field_device(d_lin, d_tiled, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_tiled.cpu().numpy(), oracle.tile_field(lin))
