@@ -67,6 +67,8 @@ SYMBOLS = {
     "crf_compute_ensemble_stat_device": (C.c_int, [_VOIDP, C.c_int, _VOIDP, _VOIDP]),
     "crf_compute_set_predicate": (C.c_int, [_VOIDP, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "crf_compute_set_predicate_device": (C.c_int, [_VOIDP, C.c_int, C.c_float, C.c_int, C.c_int, _VOIDP, _VOIDP]),
+    "crf_compute_dkl": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "crf_compute_dkl_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
     "crf_tiled_element_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "crf_tile_field_device": (C.c_int, [_VOIDP, _VOIDP, _VOIDP, _VOIDP]),
     "crf_set_profiling": (C.c_int, [_VOIDP, C.c_int]),

@@ -730,6 +730,52 @@ int crf_compute_set_predicate(crf_context* c, int op, float comparison_value, in
     return CRF_OK;
 }
 
+int crf_compute_dkl_device(crf_context* c, int estimator, int num_bins, int k, void* device_out, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!device_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (estimator != CRF_DKL_BINNED && estimator != CRF_DKL_ENTROPY_KNN)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("unknown DKL estimator %d", estimator));
+    if (c->cs > crf::kMaxGenericMembers)
+        return fail(c, CRF_ERR_UNSUPPORTED, fmt("DKL supports at most %d members", crf::kMaxGenericMembers));
+    if (estimator == CRF_DKL_BINNED && (num_bins < 1 || num_bins > 1024))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,1024]", num_bins));
+    if (estimator == CRF_DKL_ENTROPY_KNN && c->cs > 1 && (k < 1 || k >= c->cs))
+        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs-1=%d]", k, c->cs - 1));
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (int r = ensure_workspace(c, crf::dkl_workspace_bytes(c->cs, estimator, num_bins, c->num_voxels))) return r;
+    // psi(n) = -gamma + H_{n-1} (boost::math::digamma at positive integers, DKL.cpp:156)
+    auto psi = [](int n) {
+        long double h = 0.0L;
+        for (int i = 1; i < n; i++) h += 1.0L / (long double)i;
+        return double(h - 0.577215664901532860606512090082402431L);
+    };
+    const double knn_const = estimator == CRF_DKL_ENTROPY_KNN && c->cs > 1 ? psi(c->cs) - psi(k) + std::log(2.0) : 0.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = take_event(c);
+        e1 = take_event(c);
+    }
+    crf::LaunchInfo info;
+    hipError_t e = crf::launch_dkl(c->d_member_table, c->cs, c->num_voxels, estimator, num_bins, k, knn_const,
+                                   c->d_workspace, static_cast<float*>(device_out), s, e0, e1, &info);
+    c->last_kernel = info.kernel_name ? info.kernel_name : "";
+    if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+    if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+    return CRF_OK;
+}
+
+int crf_compute_dkl(crf_context* c, int estimator, int num_bins, int k, float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
+    if (int r = bind_device(c)) return r;
+    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
+    if (int r = crf_compute_dkl_device(c, estimator, num_bins, k, c->d_out, nullptr)) return r;
+    CRF_HIP(c, hipMemcpyAsync(host_out, c->d_out, c->num_voxels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
 size_t crf_tiled_element_count(int xs, int ys, int zs) {
     if (xs <= 0 || ys <= 0 || zs <= 0) return 0;
     return size_t((xs + 7) / 8) * size_t((ys + 7) / 8) * size_t((zs + 3) / 4) * 256;

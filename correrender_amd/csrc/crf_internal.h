@@ -101,6 +101,12 @@ hipError_t launch_set_predicate(const float* const* d_members, int cs, size_t nu
                                 hipEvent_t ev_end, LaunchInfo* info);
 hipError_t launch_tile_field(const float* d_linear, float* d_tiled, int xs, int ys, int zs, hipStream_t s);
 
+// ---- kernels_dkl.hip: DKLCalculator (estimator 0 = binned, 1 = entropy k-NN) --------------------------------
+size_t dkl_workspace_bytes(int cs, int estimator, int num_bins, size_t num_voxels);
+hipError_t launch_dkl(const float* const* d_members, int cs, size_t num_voxels, int estimator, int num_bins, int k,
+                      double knn_const, unsigned char* d_workspace, float* d_out, hipStream_t s, hipEvent_t ev_begin,
+                      hipEvent_t ev_end, LaunchInfo* info);
+
 // pair-request mode (kernels_generic.hip): requests = 8 uint32 each {xi,yi,zi,i,xj,yj,zj,j}; voxel i is read from
 // d_members_i, voxel j from d_members_j.  d_requests == nullptr: request r = voxel pair (r, r) (symmetric field mode).
 struct PairArgs {

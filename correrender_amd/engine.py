@@ -270,6 +270,24 @@ class CorrField:
             C.c_void_p(stream)))
         return out
 
+    def dkl(self, estimator, *, num_bins: int = 80, k: Optional[int] = None) -> np.ndarray:
+        """DKLCalculator::calculateCpu: KL divergence of the normalised ensemble distribution from N(0,1);
+        estimator "binned"/0 or "knn"/1; shape (zs, ys, xs)."""
+        est = {"binned": 0, "knn": 1}.get(estimator, estimator)
+        xs, ys, zs = self.grid
+        out = np.empty((zs, ys, xs), dtype=np.float32)
+        kk = int(k if k is not None else default_kraskov_k(self.cs))   # same default formula, DKLCalculator.cpp:94-101
+        self._check(self._lib.crf_compute_dkl(self._ctx, int(est), int(num_bins), kk,
+                                              out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def dkl_device(self, estimator, out, *, num_bins: int = 80, k: Optional[int] = None, stream: int = 0):
+        est = {"binned": 0, "knn": 1}.get(estimator, estimator)
+        kk = int(k if k is not None else default_kraskov_k(self.cs))
+        self._check(self._lib.crf_compute_dkl_device(self._ctx, int(est), int(num_bins), kk,
+                                                     C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
     def tiled_element_count(self) -> int:
         return int(self._lib.crf_tiled_element_count(*self.grid))
 

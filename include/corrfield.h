@@ -175,6 +175,15 @@ int crf_compute_set_predicate(crf_context* ctx, int comparison_operator, float c
 int crf_compute_set_predicate_device(crf_context* ctx, int comparison_operator, float comparison_value, int count_lower,
                                      int count_upper, void* device_out, void* stream);
 
+/* DKLCalculator::calculateCpu (src/Calculators/DKLCalculator.cpp:134-262): Kullback-Leibler divergence between the
+ * normalised distribution of the cs member values of a voxel and N(0,1).  Estimators (DKLEstimatorType,
+ * DKLCalculator.hpp:39-41): binned = computeDKLBinned<double> (DKL.cpp:38-84, num_bins in [1, 1024], default 80),
+ * entropy k-NN = computeDKLKNNEstimate<double> (DKL.cpp:98-165, 1 <= k < cs, default max(ceil(3 cs / 100), 1),
+ * DKLCalculator.cpp:94-101).  cs == 1 -> 1; a NaN member -> NaN; at most 2048 members. */
+typedef enum crf_dkl_estimator { CRF_DKL_BINNED = 0, CRF_DKL_ENTROPY_KNN = 1 } crf_dkl_estimator;
+int crf_compute_dkl(crf_context* ctx, int estimator, int num_bins, int k, float* host_out);
+int crf_compute_dkl_device(crf_context* ctx, int estimator, int num_bins, int k, void* device_out, void* stream);
+
 /* ---- result layout for the renderer -------------------------------------------------------------------------------- */
 /* The reference keeps device fields in 8x8x4 tiles (bufferTileSize, VolumeData.cpp:1581-1621; addressed by IDXS of
  * Data/Shaders/Correlation/ScalarFields.glsl:32-50): tiles in x-fastest order, x-fastest inside a tile, grid padded up

@@ -349,6 +349,122 @@ inline float mi_to_cc(float mi) {  // CorrelationCalculator.cpp:1071-1073,1130-1
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// DKLCalculator: Kullback-Leibler divergence between a voxel's normalised ensemble distribution and N(0,1)
+// (src/Calculators/DKL.cpp:38-165, driver src/Calculators/DKLCalculator.cpp:134-262, Real = double).  DKL.cpp needs
+// boost::math::digamma and sgl's Math.hpp (PI, TWO_PI, sqr, iceil) and cannot be compiled here: restated.  PARITY
+// UNPINNED for the two sgl constants: sgl declares PI / TWO_PI as `float` (so `std::log(sgl::TWO_PI)` is the float
+// overload); should a build use double constants the results move by < 1e-7 absolute, inside the stated tolerance.
+// ---------------------------------------------------------------------------------------------------------------
+static const float SGL_PI = 3.1415926535897932f;
+static const float SGL_TWO_PI = SGL_PI * 2.0f;
+
+// computeDKLBinned<double> (DKL.cpp:38-84); overwrites v with the normalised values like the reference
+static float dkl_binned_f64(float* v, int numBins, int es, std::vector<double>& hist) {
+    const double factor = 1.0 / double(es);
+    double mean = 0, variance = 0;
+    for (int c = 0; c < es; c++) mean += factor * v[c];
+    for (int c = 0; c < es; c++) {
+        const double diff = mean - v[c];
+        variance += factor * diff * diff;
+    }
+    const double stdev = std::sqrt(variance);
+    double minVal = std::numeric_limits<double>::max(), maxVal = std::numeric_limits<double>::lowest();
+    for (int c = 0; c < es; c++) {
+        const double val = (v[c] - mean) / stdev;
+        v[c] = float(val);
+        minVal = std::min(minVal, val);
+        maxVal = std::max(maxVal, val);
+    }
+    minVal -= 0.01;
+    maxVal += 0.01;
+    const double binFactor = double(numBins) / (maxVal - minVal);
+    const double binFactorInv = (maxVal - minVal) / double(numBins);
+    hist.assign(size_t(numBins), 0.0);
+    for (int c = 0; c < es; c++) {
+        const double t = (v[c] - minVal) * binFactor;
+        // int(NaN) is INT_MIN on x86-64 (cvttsd2si) and clamps to bin 0 -- spelled out instead of relying on UB
+        const int raw = std::isnan(t) ? std::numeric_limits<int>::min()
+                                      : (t >= 2147483648.0 ? std::numeric_limits<int>::min()
+                                                           : (t <= -2147483649.0 ? std::numeric_limits<int>::min() : int(t)));
+        hist[size_t(std::clamp(raw, 0, numBins - 1))] += 1.0;
+    }
+    double dkl = 0;
+    for (int b = 0; b < numBins; b++) {
+        if (hist[size_t(b)] > 0) {
+            const double px = hist[size_t(b)] / double(es);
+            const double center = (double(b) + 0.5) * binFactorInv + minVal;
+            dkl += std::log(px * binFactor / (std::sqrt(0.5 / double(SGL_PI)) * std::exp(-0.5 * (center * center)))) * px;
+        }
+    }
+    if (std::isinf(dkl)) return std::numeric_limits<float>::quiet_NaN();
+    return float(dkl);
+}
+
+// findKNearestNeighbors<float> (DKL.cpp:98-130): distance from data[i] to the farther end of a window of k+1
+// consecutive sorted values containing i, the window placed by a step-halving descent (NOT an exhaustive search).
+// `data` is the float array, so the template deduces Real = float even inside computeDKLKNNEstimate<double>.
+static float dkl_window_distance(const float* data, int N, int k, int i) {
+    const float big = std::numeric_limits<float>::max();
+    int step = (k + 1) / 2;  // sgl::iceil(k, 2)
+    int l = std::max(i - step, 0);
+    int r = l + k;
+    if (r >= N) {
+        r = N - 1;
+        l = N - k - 1;
+    }
+    const float vc = data[i];
+    while (true) {
+        const float vl = l >= 0 ? vc - data[l] : big;
+        const float vr = r < N ? data[r] - vc : big;
+        const float diff = std::max(vl, vr);
+        const float vl0 = (l - step <= i && l - step >= 0) ? vc - data[l - step] : big;
+        const float vr0 = (r - step >= i && r - step < N) ? data[r - step] - vc : big;
+        const float diff0 = std::max(vl0, vr0);
+        const float vl1 = (l + step <= i && l + step >= 0) ? vc - data[l + step] : big;
+        const float vr1 = (r + step >= i && r + step < N) ? data[r + step] - vc : big;
+        const float diff1 = std::max(vl1, vr1);
+        const float d01 = diff0 - diff1;
+        int dir = d01 > 0.0f ? 1 : (d01 < 0.0f ? -1 : 0);
+        if (diff < diff0 && diff < diff1) dir = 0;
+        l += dir * step;
+        r += dir * step;
+        if (step == 1) break;
+        step = (step + 1) / 2;
+    }
+    return std::max(vc - data[l], data[r] - vc);
+}
+
+// computeDKLKNNEstimate<double> (DKL.cpp:132-165): Kozachenko-Leonenko entropy estimate of the normalised sample
+static float dkl_knn_f64(float* v, int k, int es, const DigammaTable& psi) {
+    const double factor = 1.0 / double(es);
+    double mean = 0, variance = 0;
+    for (int c = 0; c < es; c++) mean += factor * v[c];
+    for (int c = 0; c < es; c++) {
+        const double diff = mean - v[c];
+        variance += factor * diff * diff;
+    }
+    const double stdev = std::sqrt(variance);
+    bool anyNan = false;
+    for (int c = 0; c < es; c++) {
+        v[c] = float((v[c] - mean) / stdev);
+        anyNan = anyNan || std::isnan(v[c]);
+    }
+    if (anyNan) return std::numeric_limits<float>::quiet_NaN();  // stdev == 0: every later term is NaN (no sort of NaNs)
+    std::sort(v, v + es);
+    double entropy = 0, secondMoment = 0;
+    for (int c = 0; c < es; c++) {
+        const double nnDist = dkl_window_distance(v, es, k, c);
+        entropy += factor * std::log(nnDist);
+        const double value = v[c];
+        secondMoment += factor * value * value;
+    }
+    entropy += psi.v[size_t(es)] - psi.v[size_t(k)] + std::log(2.0);
+    float dkl = float(-entropy + 0.5 * double(std::log(SGL_TWO_PI)) + 0.5 * secondMoment);
+    if (std::isinf(dkl)) return std::numeric_limits<float>::quiet_NaN();
+    return std::max(dkl, 0.0f);
+}
+
 extern "C" {
 
 enum {
@@ -679,6 +795,41 @@ int oracle_set_predicate(int op, float comparisonValue, int countLower, int coun
             out[p] = std::clamp(float(count) - float(countLower), 0.0f, 1.0f);
         } else {
             out[p] = std::clamp((float(count) - float(countLower)) / (float(countUpper) - float(countLower)), 0.0f, 1.0f);
+        }
+    }
+    return 0;
+}
+
+/*
+ * DKLCalculator::calculateCpu (DKLCalculator.cpp:134-262): estimator 0 = binned (numBins), 1 = entropy k-NN (k);
+ * cs == 1 -> 1.0; a NaN member value -> NaN.  Requires 1 <= k < cs for the k-NN estimator.
+ */
+int oracle_dkl_field(int estimator, const float* const* fields, int cs, size_t numPoints, int numBins, int k, float* out) {
+    if (cs < 1 || (estimator != 0 && estimator != 1)) return 1;
+    if (estimator == 1 && cs > 1 && (k < 1 || k >= cs)) return 1;
+    if (estimator == 0 && numBins < 1) return 1;
+    DigammaTable psi;
+    psi.ensure(cs);
+#pragma omp parallel
+    {
+        std::vector<float> vals((size_t)cs);
+        std::vector<double> hist;
+#pragma omp for schedule(static)
+        for (long long p = 0; p < (long long)numPoints; p++) {
+            if (cs == 1) {
+                out[p] = 1.0f;
+                continue;
+            }
+            bool isNan = false;
+            for (int c = 0; c < cs; c++) {
+                vals[size_t(c)] = fields[c][p];
+                isNan = isNan || std::isnan(vals[size_t(c)]);
+            }
+            if (isNan) {
+                out[p] = std::numeric_limits<float>::quiet_NaN();
+                continue;
+            }
+            out[p] = estimator == 0 ? dkl_binned_f64(vals.data(), numBins, cs, hist) : dkl_knn_f64(vals.data(), k, cs, psi);
         }
     }
     return 0;

@@ -55,6 +55,8 @@ class Oracle:
                                              C.c_size_t, FP]
         lib.oracle_tile_field.restype = None
         lib.oracle_tile_field.argtypes = [FP, C.c_int, C.c_int, C.c_int, FP]
+        lib.oracle_dkl_field.restype = C.c_int
+        lib.oracle_dkl_field.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int, C.c_int, FP]
         lib.oracle_max_threads.restype = C.c_int
         lib.oracle_ensemble_stat.restype = C.c_int
         lib.oracle_ensemble_stat.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, FP]
@@ -152,6 +154,15 @@ class Oracle:
         lin = _f32(linear)
         out = np.empty(((xs + 7) // 8) * ((ys + 7) // 8) * ((zs + 3) // 4) * 256, np.float32)
         self.lib.oracle_tile_field(_fp(lin), xs, ys, zs, _fp(out))
+        return out
+
+    def dkl(self, estimator, members, *, num_bins=80, k=3):
+        """DKLCalculator::calculateCpu: estimator 0 = binned, 1 = entropy k-NN."""
+        members = _members(members)
+        ptrs = (C.c_void_p * len(members))(*[m.ctypes.data for m in members])
+        out = np.empty(members[0].size, np.float32)
+        assert self.lib.oracle_dkl_field(int(estimator), ptrs, len(members), members[0].size, int(num_bins), int(k),
+                                         _fp(out)) == 0
         return out
 
     def max_threads(self):
