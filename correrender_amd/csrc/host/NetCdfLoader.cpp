@@ -1,0 +1,296 @@
+// NetCdfLoader.cpp -- see NetCdfLoader.hpp.  File format: "The NetCDF Classic Format Specification" (header grammar:
+// magic numrecs dim_list gatt_list var_list; all integers big-endian, names and values padded to 4 bytes).
+#include "NetCdfLoader.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "Calculator.hpp"
+#include "VolumeData.hpp"
+
+namespace crfhost {
+
+namespace {
+enum { NC_BYTE = 1, NC_CHAR = 2, NC_SHORT = 3, NC_INT = 4, NC_FLOAT = 5, NC_DOUBLE = 6 };
+enum { TAG_DIMENSION = 0x0A, TAG_VARIABLE = 0x0B, TAG_ATTRIBUTE = 0x0C };
+
+size_t typeSize(int type) {
+    switch (type) {
+        case NC_BYTE:
+        case NC_CHAR: return 1;
+        case NC_SHORT: return 2;
+        case NC_INT:
+        case NC_FLOAT: return 4;
+        case NC_DOUBLE: return 8;
+        default: return 0;
+    }
+}
+
+// sequential big-endian reader over the header
+struct Cursor {
+    FILE* f;
+    const std::string& path;
+    void bytes(void* dst, size_t n) {
+        if (n && std::fread(dst, 1, n, f) != n) throw CalculatorError("Error in NetCdfLoader: truncated header in \"" + path + "\".");
+    }
+    uint32_t u32() {
+        unsigned char b[4];
+        bytes(b, 4);
+        return (uint32_t(b[0]) << 24) | (uint32_t(b[1]) << 16) | (uint32_t(b[2]) << 8) | uint32_t(b[3]);
+    }
+    uint64_t u64() {
+        const uint64_t hi = u32();
+        return (hi << 32) | u32();
+    }
+    void skipPadding(uint64_t n) {
+        const uint64_t pad = (4 - (n & 3)) & 3;
+        unsigned char b[4];
+        bytes(b, size_t(pad));
+    }
+    std::string name() {
+        const uint32_t n = u32();
+        if (n > (1u << 20)) throw CalculatorError("Error in NetCdfLoader: implausible name length in \"" + path + "\".");
+        std::string s(n, '\0');
+        bytes(s.data(), n);
+        skipPadding(n);
+        return s;
+    }
+};
+
+float beFloat(const unsigned char* p) {
+    const uint32_t u = (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]);
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+double beDouble(const unsigned char* p) {
+    uint64_t u = 0;
+    for (int i = 0; i < 8; i++) u = (u << 8) | p[i];
+    double d;
+    std::memcpy(&d, &u, 8);
+    return d;
+}
+
+bool isOneOf(const std::string& s, std::initializer_list<const char*> names) {
+    for (const char* n : names)
+        if (s == n) return true;
+    return false;
+}
+}  // namespace
+
+void NetCdfLoader::error(const std::string& msg) const {
+    throw CalculatorError("Error in NetCdfLoader: " + msg + " (file \"" + path + "\").");
+}
+
+NetCdfLoader::~NetCdfLoader() {
+    if (file) std::fclose(file);
+}
+
+uint64_t NetCdfLoader::dimLength(int dimid) const {
+    const Dim& d = dims.at(size_t(dimid));
+    return d.length == 0 ? numRecs : d.length;
+}
+
+NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
+    file = std::fopen(path.c_str(), "rb");
+    if (!file) error("file could not be opened");
+    Cursor c{file, path};
+    unsigned char magic[4];
+    c.bytes(magic, 4);
+    if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F')
+        error("NetCDF-4 (HDF5 container) is not supported by this build (no libhdf5); convert with `nccopy -k classic`");
+    if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F') error("not a NetCDF classic file");
+    version = magic[3];
+    if (version == 5) error("CDF-5 (64-bit data) is not supported; convert with `nccopy -k 64-bit-offset`");
+    if (version != 1 && version != 2) error("unknown NetCDF classic version byte");
+    const uint32_t recs = c.u32();
+    numRecs = recs == 0xFFFFFFFFu ? 0 : recs;  // STREAMING: record count not recorded; fixed by the file size below
+
+    auto listHeader = [&](uint32_t expectedTag) -> uint32_t {
+        const uint32_t tag = c.u32(), n = c.u32();
+        if (tag == 0 && n == 0) return 0;  // ABSENT
+        if (tag != expectedTag) error("malformed header (unexpected list tag)");
+        return n;
+    };
+    auto readAttrs = [&](std::vector<Attr>& out) {
+        const uint32_t n = listHeader(TAG_ATTRIBUTE);
+        for (uint32_t i = 0; i < n; i++) {
+            Attr a;
+            a.name = c.name();
+            a.type = int(c.u32());
+            a.nelems = c.u32();
+            const size_t ts_ = typeSize(a.type);
+            if (!ts_) error("attribute \"" + a.name + "\" has an unknown type");
+            const uint64_t nbytes = a.nelems * ts_;
+            if (nbytes > (uint64_t(1) << 28)) error("implausible attribute size");
+            a.raw.resize(size_t(nbytes));
+            c.bytes(a.raw.data(), size_t(nbytes));
+            c.skipPadding(nbytes);
+            out.push_back(std::move(a));
+        }
+    };
+
+    const uint32_t ndims = listHeader(TAG_DIMENSION);
+    for (uint32_t i = 0; i < ndims; i++) {
+        Dim d;
+        d.name = c.name();
+        d.length = c.u32();
+        dims.push_back(d);
+    }
+    std::vector<Attr> globalAttrs;
+    readAttrs(globalAttrs);
+    const uint32_t nvars = listHeader(TAG_VARIABLE);
+    for (uint32_t i = 0; i < nvars; i++) {
+        Var v;
+        v.name = c.name();
+        const uint32_t rank = c.u32();
+        if (rank > 1024) error("implausible variable rank");
+        for (uint32_t r = 0; r < rank; r++) {
+            const uint32_t id = c.u32();
+            if (id >= dims.size()) error("variable \"" + v.name + "\" refers to an unknown dimension");
+            v.dimids.push_back(int(id));
+        }
+        readAttrs(v.attrs);
+        v.type = int(c.u32());
+        v.vsize = c.u32();
+        v.begin = version == 1 ? uint64_t(c.u32()) : c.u64();
+        v.isRecord = !v.dimids.empty() && dims[size_t(v.dimids[0])].length == 0;
+        vars.push_back(std::move(v));
+    }
+
+    // record layout: records of all record variables are interleaved; the padding of vsize is omitted when there is
+    // exactly one record variable (classic format specification, "Note on padding")
+    int numRecordVars = 0;
+    for (const Var& v : vars) numRecordVars += v.isRecord ? 1 : 0;
+    for (const Var& v : vars) {
+        if (!v.isRecord) continue;
+        uint64_t slab = typeSize(v.type);
+        for (size_t d = 1; d < v.dimids.size(); d++) slab *= dims[size_t(v.dimids[d])].length;
+        recordSize += numRecordVars == 1 ? slab : ((slab + 3) & ~uint64_t(3));
+    }
+    if (recs == 0xFFFFFFFFu && recordSize > 0) {
+        uint64_t firstBegin = std::numeric_limits<uint64_t>::max();
+        for (const Var& v : vars)
+            if (v.isRecord) firstBegin = std::min(firstBegin, v.begin);
+        std::fseek(file, 0, SEEK_END);
+        const uint64_t size = uint64_t(std::ftell(file));
+        numRecs = size > firstBegin ? (size - firstBegin) / recordSize : 0;
+    }
+
+    // grid: first float/double variable with (z, y, x) trailing dimensions
+    int representative = -1;
+    for (size_t i = 0; i < vars.size() && representative < 0; i++) {
+        const Var& v = vars[i];
+        if ((v.type != NC_FLOAT && v.type != NC_DOUBLE) || (v.dimids.size() != 3 && v.dimids.size() != 4)) continue;
+        representative = int(i);
+    }
+    if (representative < 0) error("no 3-D or 4-D floating-point variable found");
+    {
+        const Var& v = vars[size_t(representative)];
+        const size_t r = v.dimids.size();
+        zs = int(dimLength(v.dimids[r - 3]));
+        ys = int(dimLength(v.dimids[r - 2]));
+        xs = int(dimLength(v.dimids[r - 1]));
+        const std::string &nz = dims[size_t(v.dimids[r - 3])].name, &ny = dims[size_t(v.dimids[r - 2])].name,
+                          &nx = dims[size_t(v.dimids[r - 1])].name;
+        if (!isOneOf(nz, {"z", "zs", "lev"}) || !isOneOf(ny, {"y", "ys", "lat"}) || !isOneOf(nx, {"x", "xs", "lon"}))
+            warnings.push_back("dimensions (" + nz + ", " + ny + ", " + nx + ") taken positionally as (z, y, x)");
+        if (r == 4) {
+            const std::string& lead = dims[size_t(v.dimids[0])].name;
+            const int n = int(dimLength(v.dimids[0]));
+            if (lead == "time") {
+                ts = n;
+            } else if (isOneOf(lead, {"ensemble", "member", "members"})) {
+                es = n;
+            } else {
+                warnings.push_back("Warning in NetCdfLoader::setInputFiles: Unknown dimension name. Assuming time.");
+                ts = n;
+            }
+        }
+    }
+    if (xs <= 0 || ys <= 0 || zs <= 0) error("empty grid");
+
+    for (size_t i = 0; i < vars.size(); i++) {
+        const Var& v = vars[i];
+        if ((v.type != NC_FLOAT && v.type != NC_DOUBLE) || (v.dimids.size() != 3 && v.dimids.size() != 4)) continue;
+        const size_t r = v.dimids.size();
+        if (int(dimLength(v.dimids[r - 3])) != zs || int(dimLength(v.dimids[r - 2])) != ys ||
+            int(dimLength(v.dimids[r - 1])) != xs)
+            continue;
+        if (r == 4 && int(dimLength(v.dimids[0])) != (ts > 1 ? ts : es) && !(ts == 1 && es == 1)) continue;
+        Field f{v.name, int(i), false, std::numeric_limits<float>::quiet_NaN()};
+        for (const Attr& a : v.attrs) {
+            if (a.name == "standard_name" && a.type == NC_CHAR) {
+                f.name.assign(reinterpret_cast<const char*>(a.raw.data()), a.raw.size());
+                while (!f.name.empty() && f.name.back() == '\0') f.name.pop_back();
+            } else if ((a.name == "missing_value" || a.name == "_FillValue") && a.nelems >= 1) {
+                if (a.type == NC_FLOAT) {
+                    f.hasFill = true;
+                    f.fillValue = beFloat(a.raw.data());
+                } else if (a.type == NC_DOUBLE) {
+                    f.hasFill = true;
+                    f.fillValue = float(beDouble(a.raw.data()));
+                }
+            }
+        }
+        fields.push_back(f);
+        fieldNames.push_back(f.name);
+    }
+}
+
+// one xs*ys*zs slab: the whole variable (rank 3) or index `leadingIndex` of its first dimension (rank 4)
+void NetCdfLoader::readSlab(const Var& v, uint64_t leadingIndex, float* out) const {
+    const uint64_t n = uint64_t(xs) * uint64_t(ys) * uint64_t(zs);
+    const size_t es_ = typeSize(v.type);
+    uint64_t offset = v.begin;
+    if (v.dimids.size() == 4) {
+        if (leadingIndex >= dimLength(v.dimids[0])) error("index outside the leading dimension of \"" + v.name + "\"");
+        offset += v.isRecord ? leadingIndex * recordSize : leadingIndex * n * es_;
+    } else if (v.isRecord) {
+        error("3-D record variables (an UNLIMITED z axis) are not supported");
+    }
+    std::vector<unsigned char> raw(size_t(n * es_));
+#if defined(_WIN32)
+    if (_fseeki64(file, (long long)offset, SEEK_SET) != 0) error("seek failed");
+#else
+    if (fseeko(file, off_t(offset), SEEK_SET) != 0) error("seek failed");
+#endif
+    if (std::fread(raw.data(), 1, raw.size(), file) != raw.size()) error("variable \"" + v.name + "\" is truncated");
+    if (v.type == NC_FLOAT) {
+        for (uint64_t i = 0; i < n; i++) out[i] = beFloat(raw.data() + 4 * i);
+    } else {
+        for (uint64_t i = 0; i < n; i++) out[i] = float(beDouble(raw.data() + 8 * i));
+    }
+}
+
+void NetCdfLoader::getFieldEntry(const std::string& fieldName, int timeStepIdx, int memberIdx, float* out) const {
+    const Field* field = nullptr;
+    for (const Field& f : fields)
+        if (f.name == fieldName) field = &f;
+    if (!field) error("Error in NetCdfLoader::getFieldEntry: Unknown field name \"" + fieldName + "\"");
+    const Var& v = vars[size_t(field->var)];
+    uint64_t lead = 0;
+    if (v.dimids.size() == 4) lead = uint64_t(ts > 1 ? timeStepIdx : (es > 1 ? memberIdx : 0));  // :869-875
+    readSlab(v, lead, out);
+    if (field->hasFill) {
+        const size_t n = size_t(xs) * size_t(ys) * size_t(zs);
+        for (size_t i = 0; i < n; i++)
+            if (out[i] == field->fillValue) out[i] = std::numeric_limits<float>::quiet_NaN();
+    }
+}
+
+std::shared_ptr<VolumeData> NetCdfLoader::createVolumeData() const {
+    auto vol = std::make_shared<VolumeData>(xs, ys, zs, ts, es);
+    std::vector<float> buffer(size_t(xs) * size_t(ys) * size_t(zs));
+    for (const std::string& name : fieldNames)
+        for (int t = 0; t < ts; t++)
+            for (int e = 0; e < es; e++) {
+                getFieldEntry(name, t, e, buffer.data());
+                vol->setFieldData(name, t, e, buffer.data());
+            }
+    return vol;
+}
+
+}  // namespace crfhost

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "CorrelationCalculator.hpp"
+#include "NetCdfLoader.hpp"
 
 using namespace crfhost;
 
@@ -174,10 +175,43 @@ static int testCompute(const char* inPath, const std::string& outDir) {
     return 0;
 }
 
+// netcdf <file> <outdir>: CPU only -- parses the file, prints the metadata, dumps every (field, t, e) volume.
+// netcdf_compute <file> <outdir>: GPU -- the file's first field through CorrelationCalculator (Pearson, grid centre).
+static int testNetCdf(const char* file, const std::string& outDir, bool compute) {
+    NetCdfLoader loader(file);
+    std::printf("grid %d %d %d ts %d es %d\n", loader.getGridSizeX(), loader.getGridSizeY(), loader.getGridSizeZ(),
+                loader.getTimeStepCount(), loader.getEnsembleMemberCount());
+    for (const auto& name : loader.getFieldNames()) std::printf("field %s\n", name.c_str());
+    for (const auto& w : loader.getWarnings()) std::printf("warning %s\n", w.c_str());
+    const size_t n = size_t(loader.getGridSizeX()) * loader.getGridSizeY() * loader.getGridSizeZ();
+    if (!compute) {
+        std::vector<float> buffer(n);
+        for (const auto& name : loader.getFieldNames())
+            for (int t = 0; t < loader.getTimeStepCount(); t++)
+                for (int e = 0; e < loader.getEnsembleMemberCount(); e++) {
+                    loader.getFieldEntry(name, t, e, buffer.data());
+                    dump(outDir + "/" + name + "_t" + std::to_string(t) + "_e" + std::to_string(e) + ".bin", buffer.data(), n);
+                }
+        std::puts("NETCDF-OK");
+        return 0;
+    }
+    auto vol = loader.createVolumeData();
+    auto calc = std::make_shared<CorrelationCalculator>(0);
+    vol->addCalculator(calc);
+    calc->setSettings(SettingsMap{{"correlation_measure_type", "pearson"}});
+    vol->updateCalculators();
+    HostCacheEntry entry = vol->getFieldEntryCpu(FieldType::SCALAR, calc->getOutputFieldName(), 0, 0);
+    dump(outDir + "/pearson.bin", entry->data<float>(), n);
+    std::puts("NETCDF-COMPUTE-OK");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "settings") return testSettings();
         if (argc >= 4 && std::string(argv[1]) == "compute") return testCompute(argv[2], argv[3]);
+        if (argc >= 4 && std::string(argv[1]) == "netcdf") return testNetCdf(argv[2], argv[3], false);
+        if (argc >= 4 && std::string(argv[1]) == "netcdf_compute") return testNetCdf(argv[2], argv[3], true);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 2;
