@@ -152,6 +152,34 @@ struct SortNet32<64> {
     }
 };
 template <>
+struct SortNet32<48> {
+    static __device__ __forceinline__ void sort(uint32_t (&a)[48]) {
+#define CRF_SORTNET_N 48
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet32<80> {
+    static __device__ __forceinline__ void sort(uint32_t (&a)[80]) {
+#define CRF_SORTNET_N 80
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet32<96> {
+    static __device__ __forceinline__ void sort(uint32_t (&a)[96]) {
+#define CRF_SORTNET_N 96
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet32<112> {
+    static __device__ __forceinline__ void sort(uint32_t (&a)[112]) {
+#define CRF_SORTNET_N 112
+#include "sortnet.inc"
+    }
+};
+template <>
 struct SortNet32<128> {
     static __device__ __forceinline__ void sort(uint32_t (&a)[128]) {
 #define CRF_SORTNET_N 128

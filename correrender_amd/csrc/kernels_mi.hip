@@ -127,25 +127,33 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     const bool ref_all_valid = prep[N] != 0;
     const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + kBinnedSxOffset);
 
+    // cs is padded to the next multiple of 16 (launch_mi_binned): only the last 16 slots can be padding
+    constexpr int kFirstGuarded = EXACT ? N : N - 16;
+    const auto is_member = [cs](int e) { return e < kFirstGuarded || e < cs; };  // folds in the unrolled loops
     uint32_t a[N];
     bool is_nan = false;
     int total = 0;
     const float range_q = max_q - min_q;
     const double nbd = double(nb);
+    {
+        // all loads first, branch free: a slot past cs loads at an out-of-range offset (0, no memory request) and its
+        // code is forced to the pad code below
+        float y[N];
 #pragma unroll
-    for (int e = 0; e < N; e++) {
-        if (EXACT || e < cs) {
-            const float y = load_member_nt(members[e], bytes, byte_offset);
-            is_nan |= (y != y);
-            const float q01 = (y - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
-            const int b0 = prep[e];
-            const bool valid = (q01 == q01) && b0 != kInvalidBin;
+        for (int e = 0; e < N; e++)
+            y[e] = load_member_nt(members[is_member(e) ? e : cs - 1], bytes,
+                                  is_member(e) ? byte_offset : kOutOfRangeOffset);
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool member = is_member(e);
+            is_nan |= member && (y[e] != y[e]);
+            const float q01 = (y[e] - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
+            const int b0 = prep[e];                      // pads: kInvalidBin (binned_prep_kernel)
+            const bool valid = member && (q01 == q01) && b0 != kInvalidBin;
             int b1 = int(double(q01) * nbd);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
             a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
             total += valid ? 1 : 0;
-        } else {
-            a[e] = kPadCode;
         }
     }
     const bool slow = (total != cs) || !ref_all_valid;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     if (any_slow) {
 #pragma unroll
         for (int e = 0; e < N; e++)
-            if (EXACT || e < cs) codes[e * 64 + lane] = uint16_t(a[e] & 0xFFFFu);  // pad -> 0xFFFF
+            if (is_member(e)) codes[e * 64 + lane] = uint16_t(a[e] & 0xFFFFu);  // pad -> 0xFFFF
     }
 
     SortNet32<N>::sort(a);
@@ -161,18 +169,19 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     uint32_t cell_len = 0, col_len = 0;
 #pragma unroll
     for (int p = 0; p < N; p++) {
-        if (EXACT || p < cs) {
-            uint32_t next = kPadCode;
-            if (p + 1 < N && (EXACT || p + 1 < cs)) next = a[p + 1];
-            cell_len++;
-            col_len++;
-            const bool end_cell = next != a[p];
-            const bool end_col = (next >> 8) != (a[p] >> 8);
-            joint += T[end_cell ? cell_len : 0u];
-            mi_y -= T[end_col ? col_len : 0u];
-            cell_len = end_cell ? 0u : cell_len;
-            col_len = end_col ? 0u : col_len;
-        }
+        // guarded instantiation: the cs - total .. pads (kPadCode, the largest code) sort behind the real samples;
+        // a pad position contributes T[0] = 0
+        const bool member = is_member(p);
+        uint32_t next = kPadCode;
+        if (p + 1 < N) next = is_member(p + 1) ? a[p + 1] : kPadCode;
+        cell_len++;
+        col_len++;
+        const bool end_cell = member && next != a[p];
+        const bool end_col = member && (next >> 8) != (a[p] >> 8);
+        joint += T[end_cell ? cell_len : 0u];
+        mi_y -= T[end_col ? col_len : 0u];
+        cell_len = end_cell ? 0u : cell_len;
+        col_len = end_col ? 0u : col_len;
     }
     double mi = mi_y + joint;
 
@@ -471,7 +480,12 @@ void launch_binned_n(const float* const* d_members, const int* prep, const doubl
                            tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
 }
 
-int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
+
+// waves/SIMD the binned kernel is compiled for; CRF_BINNED_WAVES overrides for tuning (tools/tune_pearson.py)
+int env_binned_waves(int fallback) {
+    const char* v = getenv("CRF_BINNED_WAVES");
+    return (v && *v) ? atoi(v) : fallback;
+}
 
 }  // namespace
 
@@ -497,16 +511,34 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    const int n_pad = pad_pow2(cs);
+    const int n_pad = (cs + 15) / 16 * 16;
     int* prep = reinterpret_cast<int*>(d_prep);
     const double* tableT = d_tables + (cs + 1);
     launch_binned_prep(ref, d_members, cs, n_pad, a, tableT, prep, s);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    // waves/SIMD per size from measurements at 256^3 (profiles/tuning_r01.md): 64 members 1.61 ms at 2 waves (2.0 ms at
+    // 4, with scratch), 128 members 5.0 ms at 1 wave (5.7 ms at 2)
+    const int waves = env_binned_waves(0);
     switch (n_pad) {
         case 16: launch_binned_n<16, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
         case 32: launch_binned_n<32, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
-        case 64: launch_binned_n<64, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
-        default: launch_binned_n<128, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 48: launch_binned_n<48, 3>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 64:
+            switch (waves) {
+                case 3: launch_binned_n<64, 3>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+                case 4: launch_binned_n<64, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+                default: launch_binned_n<64, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+            }
+            break;
+        case 80: launch_binned_n<80, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 96: launch_binned_n<96, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 112: launch_binned_n<112, 1>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        default:
+            switch (waves) {
+                case 2: launch_binned_n<128, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+                default: launch_binned_n<128, 1>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+            }
+            break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "mi_binned_kernel";

@@ -38,7 +38,7 @@ def _check(engine, oracle, ens, measure, omeasure, what, ref_xyz=(1, 2, 3), min_
     return got, want
 
 
-@pytest.mark.parametrize("cs", [2, 5, 16, 33, 64, 100, 128])
+@pytest.mark.parametrize("cs", [2, 5, 16, 17, 33, 40, 48, 50, 64, 72, 80, 96, 100, 112, 128])
 @pytest.mark.parametrize("num_bins", [10, 80, 100])
 def test_binned_member_counts_and_bins(engine, oracle, cs, num_bins):
     ens = synth.box_ensemble(20, 12, 9, cs, seed=200 + cs)
