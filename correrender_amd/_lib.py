@@ -30,7 +30,8 @@ class CrfParams(C.Structure):
         ("min_query", C.c_float), ("max_query", C.c_float),
         ("reference_values", C.POINTER(C.c_float)),
         ("flags", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("prepared_slot", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -59,6 +60,8 @@ SYMBOLS = {
     "crf_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_gather_reference": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "crf_gather_reference_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
+    "crf_gather_reference_rows_device": (C.c_int, [_VOIDP, C.POINTER(C.c_int32), C.c_int, _VOIDP, _VOIDP]),
+    "crf_prepare_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_int, _VOIDP]),
     "crf_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
     "crf_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, _VOIDP, _VOIDP]),
     "crf_compute_requests": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_size_t, C.POINTER(C.c_float)]),

@@ -52,6 +52,7 @@ struct crf_context {
     // scratch
     float* d_ref = nullptr;    // cs reference values
     float* d_prep = nullptr;   // crf::kPrepBytes
+    float* d_prep_slots = nullptr;  // CRF_PREPARED_SLOTS x crf::kPrepBytes, lazily (crf_prepare_device)
     float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
     double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
     uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
@@ -179,7 +180,7 @@ hipEvent_t take_event(crf_context* c) {
 
 extern "C" {
 
-int crf_abi_version(void) { return 2; }
+int crf_abi_version(void) { return 3; }
 
 const char* crf_last_error(const crf_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -234,6 +235,7 @@ void crf_destroy(crf_context* c) {
     if (c->d_sec_table) (void)hipFree(c->d_sec_table);
     if (c->d_ref) (void)hipFree(c->d_ref);
     if (c->d_prep) (void)hipFree(c->d_prep);
+    if (c->d_prep_slots) (void)hipFree(c->d_prep_slots);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_todo) (void)hipFree(c->d_todo);
@@ -465,6 +467,24 @@ int crf_gather_reference_device(crf_context* c, int x, int y, int z, void* devic
     return CRF_OK;
 }
 
+int crf_gather_reference_rows_device(crf_context* c, const int32_t* xyz, int num_rows, void* device_rows, void* stream) {
+    if (int r = check_ready(c)) return r;
+    if (!xyz || !device_rows) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (num_rows < 0 || num_rows > crf::kMaxGatherRows)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("num_rows %d outside [0,%d]", num_rows, crf::kMaxGatherRows));
+    crf::GatherRows rows;
+    for (int r = 0; r < num_rows; r++) {
+        rows.voxel[r] = crf::kNoVoxel;
+        if (xyz[3 * r + 2] >= 0)
+            if (int e = ref_voxel(c, xyz[3 * r], xyz[3 * r + 1], xyz[3 * r + 2], &rows.voxel[r])) return e;
+    }
+    if (int r = bind_device(c)) return r;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    CRF_HIP(c, crf::launch_gather_reference_rows(c->d_member_table, c->cs, rows, num_rows,
+                                                 static_cast<float*>(device_rows), s));
+    return CRF_OK;
+}
+
 int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
     if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
     if (int r = crf_gather_reference_device(c, x, y, z, c ? c->d_ref : nullptr, nullptr)) return r;
@@ -473,10 +493,12 @@ int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
     return CRF_OK;
 }
 
-int crf_compute_device(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
-                       void* stream) {
+// phase: bit 0 = reference-side preparation, bit 1 = per-voxel kernel (crf_internal.h RefSource::phase);
+// slot < 0: the context's own preparation buffer
+static int compute_impl(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                        void* stream, unsigned phase, int slot) {
     if (int r = check_ready(c)) return r;
-    if (!p || !device_out) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (!p || (!device_out && (phase & 2u))) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (p->measure < CRF_PEARSON || p->measure > CRF_KMI_CC)
         return fail(c, CRF_ERR_ARGUMENT, fmt("unknown measure %d", p->measure));
     for (int v : p->reserved)
@@ -484,12 +506,24 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     float* out = static_cast<float*>(device_out);
-    if (p->flags & CRF_FLAG_SYMMETRIC) return compute_symmetric(c, p, out, s);
+    if (p->flags & CRF_FLAG_SYMMETRIC) {
+        if (phase != 3u) return fail(c, CRF_ERR_ARGUMENT, "the symmetric mode has no reference-side preparation");
+        return compute_symmetric(c, p, out, s);
+    }
+    float* prep = c->d_prep;
+    if (slot >= 0) {
+        if (!c->d_prep_slots)
+            CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_prep_slots), size_t(CRF_PREPARED_SLOTS) * crf::kPrepBytes));
+        prep = c->d_prep_slots + size_t(slot) * (crf::kPrepBytes / sizeof(float));
+    }
 
     // 1. reference vector (CorrelationCalculator.cpp:802-818): a device array, a host array (copied stream-ordered),
     //    or the reference point -- then the gather is fused into the estimator's preparation kernel.
     crf::RefSource ref{static_cast<const float*>(device_reference_values), 0};
-    if (!ref.values && (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY)) {
+    ref.phase = phase;
+    if (!(phase & 1u)) {
+        ref.values = nullptr;  // prepared earlier: no reference vector is read
+    } else if (!ref.values && (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY)) {
         if (c->sec_members.empty())
             return fail(c, CRF_ERR_STATE, "CRF_FLAG_REFERENCE_FROM_SECONDARY needs secondary members");
         size_t voxel;
@@ -497,7 +531,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         CRF_HIP(c, crf::launch_gather_reference(c->d_sec_table, c->cs, voxel, c->d_ref, s));
         ref.values = c->d_ref;
     }
-    if (!ref.values) {
+    if ((phase & 1u) && !ref.values) {
         if (p->reference_values) {
             CRF_HIP(c, hipMemcpyAsync(c->d_ref, p->reference_values, sizeof(float) * size_t(c->cs),
                                       hipMemcpyHostToDevice, s));
@@ -509,7 +543,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
 
     // 2. estimator
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profiling) {
+    if (c->profiling && (phase & 2u)) {
         e0 = take_event(c);
         e1 = take_event(c);
     }
@@ -535,7 +569,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         }
         crf::GenericArgs ga{p->measure, p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query, p->k,
                             p->kraskov_estimator_index == 2 ? 2 : 1};
-        e = crf::launch_generic(c->d_member_table, c->cs, c->num_voxels, ref, ga, c->d_tables, c->d_prep, c->d_workspace,
+        e = crf::launch_generic(c->d_member_table, c->cs, c->num_voxels, ref, ga, c->d_tables, prep, c->d_workspace,
                                 out, s, e0, e1, &info);
         c->last_kernel = info.kernel_name ? info.kernel_name : "";
         if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
@@ -544,7 +578,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     }
     switch (p->measure) {
         case CRF_PEARSON:
-            e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, ref, c->d_prep, out, s, e0, e1,
+            e = crf::launch_pearson(c->d_member_table, c->cs, c->num_voxels, vpt, ref, prep, out, s, e0, e1,
                                     &info);
             break;
         case CRF_SPEARMAN:
@@ -552,7 +586,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
             if (c->cs > 16 && !c->d_todo)
                 CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
-            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
+            e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, prep, c->d_todo, out, s, e0, e1,
                                      &info);
             break;
         case CRF_KENDALL:
@@ -560,7 +594,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
             if (c->cs > 16 && !c->d_todo)
                 CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
-            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, c->d_prep, c->d_todo, out, s, e0, e1,
+            e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, prep, c->d_todo, out, s, e0, e1,
                                     &info);
             break;
         case CRF_MI_BINNED:
@@ -571,7 +605,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("binned MI supports at most %d members", crf::kMaxSortMembers));
             crf::BinnedArgs a{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
                               p->measure == CRF_BINNED_MI_CC};
-            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, c->d_prep, out, s,
+            e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, prep, out, s,
                                       e0, e1, &info);
             break;
         }
@@ -583,7 +617,7 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kraskov MI supports at most %d members", crf::kMaxSortMembers));
             const int est = p->kraskov_estimator_index == 2 ? 2 : 1;  // clamp as CorrelationCalculator.cpp:765
             crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC};
-            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, c->d_prep, out, s,
+            e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, prep, out, s,
                                        e0, e1, &info);
             break;
         }
@@ -594,6 +628,23 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
         return fail(c, CRF_ERR_UNSUPPORTED, fmt("measure %d is not implemented by this build", p->measure));
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
     return CRF_OK;
+}
+
+int crf_compute_device(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                       void* stream) {
+    if (p && p->prepared_slot != 0) {
+        if (p->prepared_slot < 0 || p->prepared_slot > CRF_PREPARED_SLOTS)
+            return fail(c, CRF_ERR_ARGUMENT, fmt("prepared_slot %d outside [0,%d]", p->prepared_slot, CRF_PREPARED_SLOTS));
+        if (c && !c->d_prep_slots) return fail(c, CRF_ERR_STATE, "prepared_slot given but crf_prepare_device was never called");
+        return compute_impl(c, p, nullptr, device_out, stream, 2u, p->prepared_slot - 1);
+    }
+    return compute_impl(c, p, device_reference_values, device_out, stream, 3u, -1);
+}
+
+int crf_prepare_device(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream) {
+    if (slot < 0 || slot >= CRF_PREPARED_SLOTS)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("slot %d outside [0,%d)", slot, CRF_PREPARED_SLOTS));
+    return compute_impl(c, p, device_reference_values, nullptr, stream, 1u, slot);
 }
 
 int crf_compute(crf_context* c, const crf_params* p, float* host_out) {

@@ -25,6 +25,12 @@ constexpr size_t kBinnedSxOffset = kPrepBytes - 16;
 struct RefSource {
     const float* values;  // non-null: use values[c]
     size_t voxel;         // else: members[c][voxel]
+    // which halves of an evaluation a launcher performs: the reference-side preparation (into d_prep) and/or the
+    // per-voxel kernel (reading d_prep).  Split so that a caller can prepare several evaluations ahead of time on
+    // another stream (crf_prepare_device) and keep only the per-voxel kernels on the critical path.
+    unsigned phase = 3;
+    bool prepare() const { return (phase & 1u) != 0; }
+    bool run() const { return (phase & 2u) != 0; }
 };
 
 struct LaunchInfo {
@@ -33,6 +39,13 @@ struct LaunchInfo {
 
 // ---- kernels_common.hip -----------------------------------------------------------------------------------
 hipError_t launch_gather_reference(const float* const* d_members, int cs, size_t voxel, float* d_out, hipStream_t s);
+constexpr int kMaxGatherRows = 32;
+constexpr size_t kNoVoxel = ~size_t(0);
+struct GatherRows {
+    size_t voxel[kMaxGatherRows];  // kNoVoxel: the row is zero-filled
+};
+hipError_t launch_gather_reference_rows(const float* const* d_members, int cs, const GatherRows& rows, int num_rows,
+                                        float* d_out, hipStream_t s);
 hipError_t launch_minmax(const float* const* d_members, int cs, size_t num_voxels, uint32_t* d_keys /*[2]*/,
                          hipStream_t s);
 float minmax_key_to_float(uint32_t key);

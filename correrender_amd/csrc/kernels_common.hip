@@ -21,6 +21,28 @@ hipError_t launch_gather_reference(const float* const* d_members, int cs, size_t
     return hipGetLastError();
 }
 
+// Rows of a batched reference-vector exchange (multi-GPU: one collective per several evaluations): row r receives the
+// reference values of voxel[r], or zeros when voxel[r] == kNoVoxel (a point whose slice another rank owns) -- one
+// launch instead of a memset plus one gather per owned row.
+__global__ void gather_reference_rows_kernel(const float* const* __restrict__ members, int cs, GatherRows rows,
+                                             float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c < cs) {
+        const size_t voxel = rows.voxel[r];
+        out[size_t(r) * size_t(cs) + c] = voxel == kNoVoxel ? 0.0f : members[c][voxel];
+    }
+}
+
+hipError_t launch_gather_reference_rows(const float* const* d_members, int cs, const GatherRows& rows, int num_rows,
+                                        float* d_out, hipStream_t s) {
+    if (num_rows <= 0) return hipSuccess;
+    const int block = 64;
+    hipLaunchKernelGGL(gather_reference_rows_kernel, dim3((cs + block - 1) / block, num_rows), dim3(block), 0, s,
+                       d_members, cs, rows, d_out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Order-preserving float -> uint32 key so that unsigned atomicMin/atomicMax order like the floats do.
 __device__ __forceinline__ uint32_t float_to_key(float f) {

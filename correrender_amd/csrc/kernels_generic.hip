@@ -550,7 +550,8 @@ hipError_t launch_pair_requests(const float* const* d_members_i, const float* co
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
-    switch (a.measure) {
+    switch (ref.prepare() ? a.measure : -1) {
+        case -1: break;
         case 1: launch_spearman_prep(ref, d_members, cs, d_prep, s); break;
         case 2: launch_kendall_prep(ref, d_members, cs, cs, reinterpret_cast<int*>(d_prep), s); break;
         case 3:
@@ -565,6 +566,7 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
             break;
         default: return hipErrorInvalidValue;
     }
+    if (!ref.run()) return hipGetLastError();
     const size_t tiles = (num_voxels + 63) / 64;
     const unsigned blocks = unsigned(tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
     const bool use_lds = tile_bytes(cs) <= kLdsTileLimit;

@@ -505,6 +505,7 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
                             const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
+        if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
         if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -514,7 +515,8 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     const int n_pad = (cs + 15) / 16 * 16;
     int* prep = reinterpret_cast<int*>(d_prep);
     const double* tableT = d_tables + (cs + 1);
-    launch_binned_prep(ref, d_members, cs, n_pad, a, tableT, prep, s);
+    if (ref.prepare()) launch_binned_prep(ref, d_members, cs, n_pad, a, tableT, prep, s);
+    if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // waves/SIMD per size from measurements at 256^3 (profiles/tuning_r01.md): 64 members 1.61 ms at 2 waves (2.0 ms at
     // 4, with scratch), 128 members 5.0 ms at 1 wave (5.7 ms at 2)
@@ -549,6 +551,7 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     if (cs == 1) {
+        if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
         if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -559,7 +562,8 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     double* prep = reinterpret_cast<double*>(d_prep);
-    launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
+    if (ref.prepare()) launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
+    if (!ref.run()) return hipGetLastError();
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
     const int kk = a.k < cs - 1 ? a.k : cs - 1;

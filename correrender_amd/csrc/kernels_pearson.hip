@@ -349,13 +349,17 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           LaunchInfo* info) {
     if (cs == 1) {  // CorrelationCalculator.cpp:882-885
+        if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
         if (ev_end) (void)hipEventRecord(ev_end, s);
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    hipLaunchKernelGGL(pearson_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(float), s, ref, d_members, cs, d_prep);
+    if (ref.prepare())
+        hipLaunchKernelGGL(pearson_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(float), s, ref, d_members, cs,
+                           d_prep);
+    if (!ref.run()) return hipGetLastError();
 
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);

@@ -611,13 +611,15 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                            LaunchInfo* info) {
     bool split = false;
     if (cs == 1) {
+        if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
         if (ev_end) (void)hipEventRecord(ev_end, s);
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
-    launch_spearman_prep(ref, d_members, cs, d_prep, s);
+    if (ref.prepare()) launch_spearman_prep(ref, d_members, cs, d_prep, s);
+    if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -690,6 +692,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                           LaunchInfo* info) {
     bool split = false;
     if (cs == 1) {
+        if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
         if (ev_end) (void)hipEventRecord(ev_end, s);
@@ -698,7 +701,8 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     }
     const int n_pad = pad_pow2(cs);
     int* prep = reinterpret_cast<int*>(d_prep);
-    launch_kendall_prep(ref, d_members, cs, n_pad, prep, s);
+    if (ref.prepare()) launch_kendall_prep(ref, d_members, cs, n_pad, prep, s);
+    if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;

@@ -76,6 +76,7 @@ class ShardedCorrField:
         self._pending = []  # [(ref_xyz, slot)] prefetched, not yet consumed
         self._batch = [None, None]       # [R, cs] row buffers of prefetch_batch(), double-buffered
         self._batch_flip = 0
+        self._slots_per_batch = 32       # prepared-table slots: 2 batches x 32 rows = CRF_PREPARED_SLOTS
         self._batch_ready = [None, None]
         self._batch_done = [None, None]
         self._cuda = self.device.type == "cuda"
@@ -150,19 +151,25 @@ class ShardedCorrField:
             self._exchange(ref_xyz, buf, 0)
         self._pending.append((tuple(ref_xyz), slot))
 
-    def prefetch_batch(self, points):
+    def prefetch_batch(self, points, prepare=None):
         """Exchanges the reference vectors of SEVERAL upcoming compute() calls in one collective: every rank gathers, on
         its device, the vectors of the points whose slice it owns into the rows of a zeroed [R, cs] buffer, and one
         all-reduce(SUM) of R*cs floats gives every rank every row (a sum of one value and zeros is that value; the only
         bit pattern not preserved is -0.0, which no estimator distinguishes from +0.0).  One collective per R
         evaluations instead of one per evaluation: at 8 GPUs a 256^3 x 64 evaluation is ~0.1 ms per rank, the same order
-        as the launch latency of a collective.  Rows are consumed, in order, by the next len(points) compute() calls."""
+        as the launch latency of a collective.  Rows are consumed, in order, by the following compute() calls; a second
+        batch may be prefetched while the first is being consumed (double buffering).
+        prepare=(measure, kwargs): also run the estimator's reference-side preparation of every row on the communication
+        stream (crf_prepare_device), so that the compute() calls -- which must then use the same measure and
+        parameters -- launch only the per-voxel kernel on the critical path."""
         points = [tuple(p) for p in points]
-        if self._pending:
-            raise RuntimeError("prefetch_batch() needs all earlier prefetches to be consumed")
         torch = self._torch
         r = len(points)
         b = self._batch_flip
+        # two row buffers: one batch may be exchanged while the previous one is still being consumed (the exchange of
+        # batch i+1 then overlaps the kernels of batch i); a third would overwrite rows that are still pending
+        if any(not isinstance(slot, tuple) or slot[1] == b for _, slot in self._pending):
+            raise RuntimeError("prefetch_batch(): at most one batch may be outstanding besides the one being consumed")
         self._batch_flip ^= 1
         if self._batch[b] is None or self._batch[b].shape[0] < r:
             self._batch[b] = torch.empty((max(r, 8), self.cs), dtype=torch.float32, device=self.device)
@@ -170,10 +177,10 @@ class ShardedCorrField:
         owners = [slab_owner(self.zs, self.world, p[2]) for p in points]
 
         def fill(stream_ptr):
-            rows[:r].zero_()
-            for i, ((x, y, _), (owner, local_z)) in enumerate(zip(points, owners)):
-                if owner == self.rank:
-                    self.engine.gather_reference_device(x, y, local_z, rows[i], stream_ptr)
+            # one launch: owned rows gathered, the others zeroed
+            local = [(x, y, local_z) if owner == self.rank else None
+                     for (x, y, _), (owner, local_z) in zip(points, owners)]
+            self.engine.gather_reference_rows_device(local, rows, stream_ptr)
             if self._collectives:
                 if self._stage_through_host:
                     self._comm_stream.synchronize()
@@ -183,16 +190,34 @@ class ShardedCorrField:
                 else:
                     self._dist.all_reduce(rows[:r], op=self._dist.ReduceOp.SUM, group=self.group)
 
+        slots = None
+        if prepare is not None:
+            if r > self._slots_per_batch:
+                raise ValueError(f"at most {self._slots_per_batch} rows per prepared batch")
+            measure, pkw = prepare
+            if int(measure) in _BINNED and "minmax_ref" not in pkw:
+                mm = self.global_minmax()
+                pkw = dict(pkw, minmax_ref=mm, minmax_query=mm)
+            slots = [b * self._slots_per_batch + i for i in range(r)]
+
+        def prepare_rows(stream_ptr):
+            for i in range(r):
+                self.engine.prepare_device(measure, slots[i], device_reference=rows[i], stream=stream_ptr, **pkw)
+
         if self._cuda:
             with torch.cuda.stream(self._comm_stream):
                 if self._batch_done[b] is not None:
                     self._comm_stream.wait_event(self._batch_done[b])  # last kernel that read this batch buffer
                 fill(self._comm_stream.cuda_stream)
+                if slots is not None:
+                    prepare_rows(self._comm_stream.cuda_stream)
                 self._batch_ready[b].record(self._comm_stream)
         else:
             fill(0)
+            if slots is not None:
+                prepare_rows(0)
         for i, p in enumerate(points):
-            self._pending.append((p, ("batch", b, i, i == r - 1)))
+            self._pending.append((p, ("batch", b, i, i == r - 1, None if slots is None else (slots[i], int(measure)))))
 
     def compute(self, measure, out, ref_xyz, **kw):
         """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats), on the
@@ -216,10 +241,15 @@ class ShardedCorrField:
             cur = self._torch.cuda.current_stream(self.device)
             stream_ptr = cur.cuda_stream
         if isinstance(slot, tuple):  # a row of a batched exchange
-            _, b, row, last = slot
+            _, b, row, last, prepared = slot
             if cur is not None and row == 0:
                 cur.wait_event(self._batch_ready[b])
-            self.engine.compute_device(measure, out, device_reference=self._batch[b][row], stream=stream_ptr, **kw)
+            if prepared is not None:
+                if prepared[1] != int(measure):
+                    raise RuntimeError("compute(): the batch was prepared for a different measure")
+                self.engine.compute_device(measure, out, prepared_slot=prepared[0], stream=stream_ptr, **kw)
+            else:
+                self.engine.compute_device(measure, out, device_reference=self._batch[b][row], stream=stream_ptr, **kw)
             if cur is not None and last:
                 ev = self._torch.cuda.Event()
                 ev.record(cur)

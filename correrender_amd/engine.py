@@ -140,6 +140,15 @@ class CorrField:
         self._check(self._lib.crf_gather_reference_device(self._ctx, x, y, z, C.c_void_p(out.data_ptr()),
                                                           C.c_void_p(stream)))
 
+    def gather_reference_rows_device(self, points, out, stream: int = 0):
+        """points: local (x, y, z) per row, or None for a row to be zero-filled; out: [len(points), cs] CUDA floats."""
+        n = len(points)
+        flat = (C.c_int32 * (3 * max(n, 1)))()
+        for r, p in enumerate(points):
+            flat[3 * r], flat[3 * r + 1], flat[3 * r + 2] = (0, 0, -1) if p is None else (int(p[0]), int(p[1]), int(p[2]))
+        self._check(self._lib.crf_gather_reference_rows_device(self._ctx, flat, n, C.c_void_p(out.data_ptr()),
+                                                               C.c_void_p(stream)))
+
     # -- evaluation ---------------------------------------------------------------------------------------
     def _params(self, measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
                 reference_values, flags=0):
@@ -207,12 +216,15 @@ class CorrField:
 
     def compute_device(self, measure, out, ref=None, *, device_reference=None, stream: int = 0, k=None,
                        kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
-                       reference_values=None, symmetric=False, reference_from_secondary=False):
-        """Asynchronous, stream-ordered evaluation into a CUDA float32 tensor `out` of xs*ys*zs elements."""
+                       reference_values=None, symmetric=False, reference_from_secondary=False, prepared_slot=None):
+        """Asynchronous, stream-ordered evaluation into a CUDA float32 tensor `out` of xs*ys*zs elements.
+        prepared_slot: use the reference-side tables prepare_device() left in that slot (no reference vector is read)."""
         flags, mode = self._mode_flags(symmetric, reference_from_secondary)
         minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
                                reference_values, flags)
+        if prepared_slot is not None:
+            p.prepared_slot = int(prepared_slot) + 1
         if out.numel() != self.num_voxels or not out.is_cuda or not out.is_contiguous():
             raise ValueError("out must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
         dref = C.c_void_p(device_reference.data_ptr()) if device_reference is not None else C.c_void_p(0)
@@ -221,6 +233,22 @@ class CorrField:
         if keep is not None:  # the H2D copy of a host reference vector is asynchronous: keep it alive
             self._keep_ref = keep
         return out
+
+    PREPARED_SLOTS = 64   # CRF_PREPARED_SLOTS
+
+    def prepare_device(self, measure, slot: int, ref=None, *, device_reference=None, stream: int = 0, k=None,
+                       kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
+                       reference_values=None, reference_from_secondary=False):
+        """Reference-side preparation only (crf_prepare_device): fills slot `slot` for a later
+        compute_device(..., prepared_slot=slot) with the same measure and parameters."""
+        flags, mode = self._mode_flags(False, reference_from_secondary)
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
+        p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                               reference_values, flags)
+        dref = C.c_void_p(device_reference.data_ptr()) if device_reference is not None else C.c_void_p(0)
+        self._check(self._lib.crf_prepare_device(self._ctx, C.byref(p), dref, int(slot), C.c_void_p(stream)))
+        if keep is not None:
+            self._keep_ref = keep
 
     def compute_requests(self, measure, pairs, *, k=None, num_bins=80, absolute_value=False) -> np.ndarray:
         """Pair-request mode (the reference's CorrelationComputePass request mode / HEBChart::computeCorrelations):

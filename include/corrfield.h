@@ -69,7 +69,10 @@ typedef struct crf_params {
                                         / time-lag (reference vector taken from another field, :804-813) or a vector
                                         received from another rank. */
     int32_t flags;                   /* CRF_FLAG_* */
-    int32_t reserved[3];             /* must be 0 */
+    int32_t prepared_slot;           /* 0: the evaluation prepares its reference-side tables itself.  s+1: use the
+                                        tables crf_prepare_device left in slot s (the reference vector arguments are
+                                        then not read; the other fields must equal those given to crf_prepare_device) */
+    int32_t reserved[2];             /* must be 0 */
 } crf_params;
 
 /* useAbsoluteCorrelationMeasure of the pair-request path (HEBChartCorrelation.cpp:583-585).  The full-grid path ignores
@@ -105,7 +108,7 @@ void crf_destroy(crf_context* ctx);
 /* Last error message of this context (or of the calling thread's last failed crf_create when ctx==NULL). */
 const char* crf_last_error(const crf_context* ctx);
 /* ABI version of this header, bumped on incompatible change. */
-int crf_abi_version(void);
+int crf_abi_version(void);  /* 3: crf_params.reserved[0] became prepared_slot (same layout; 0 keeps the old meaning) */
 
 /* ---- the ensemble (replaces the fields[] gather of CorrelationCalculator.cpp:791-800) --------------------- */
 /* Declares the LOCAL grid (a whole grid, or this process's z-slab of one) and member count; drops any members. */
@@ -132,6 +135,11 @@ int crf_gather_reference(crf_context* ctx, int x, int y, int z, float* host_out)
 /* ... or to a device buffer, asynchronously on `stream` (a hipStream_t, NULL = the context's own stream). */
 int crf_gather_reference_device(crf_context* ctx, int x, int y, int z, void* device_out, void* stream);
 
+/* Batched form for the multi-GPU exchange: row r of device_rows (num_rows x cs floats, num_rows <= 32) receives the
+ * reference values of LOCAL grid point (xyz[3r], xyz[3r+1], xyz[3r+2]), or zeros when xyz[3r+2] < 0 (a point whose
+ * z-slice another process owns) -- so that one all-reduce(sum) over the processes yields every row everywhere. */
+int crf_gather_reference_rows_device(crf_context* ctx, const int32_t* xyz, int num_rows, void* device_rows, void* stream);
+
 /* ---- evaluation (replaces the hot loop CorrelationCalculator.cpp:868-1142) ------------------------------- */
 /* Synchronous, host output: what calculateCpu(t, e, buffer) does.  host_out receives xs*ys*zs floats. */
 int crf_compute(crf_context* ctx, const crf_params* params, float* host_out);
@@ -140,6 +148,16 @@ int crf_compute(crf_context* ctx, const crf_params* params, float* host_out);
  * the reference point are used).  device_out receives xs*ys*zs floats. */
 int crf_compute_device(crf_context* ctx, const crf_params* params, const void* device_reference_values,
                        void* device_out, void* stream);
+
+/* Two-phase form for pipelined callers (the multi-GPU driver): crf_prepare_device runs only the reference-side
+ * preparation of an evaluation (the reference-derived tables: Pearson/Spearman a_e, Kendall's x order and tie groups,
+ * binned reference bins, Kraskov's noisy reference coordinates) into slot `slot` (0 <= slot < CRF_PREPARED_SLOTS), e.g.
+ * on a communication stream right after the reference vectors arrive; a later crf_compute_device with
+ * params->prepared_slot = slot + 1 launches only the per-voxel kernel.  The caller orders the two calls (same stream
+ * or an event) and must not re-prepare a slot before the evaluation that reads it has been launched and ordered. */
+#define CRF_PREPARED_SLOTS 64
+int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* device_reference_values, int slot,
+                       void* stream);
 
 /* ---- pair-request evaluation (CorrelationComputePass request mode, CorrelationCalculator.hpp:250-258; CPU twin
  * HEBChart::computeCorrelations, src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600) ---------------------------- */

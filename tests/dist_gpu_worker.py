@@ -40,7 +40,10 @@ def main():
         points = [(1, 2, 0), (12, 8, zs // 2), (23, 15, zs - 1), (5, 5, 1)]
         batched = measure in (Measure.SPEARMAN, Measure.MUTUAL_INFORMATION_BINNED)
         if batched:
-            sharded.prefetch_batch(points)               # one collective for all four reference vectors
+            # one collective for all four reference vectors; for binned MI the reference-side preparation of the four
+            # evaluations runs on the communication stream as well (prepared slots)
+            prep = (measure, dict(k=2)) if measure == Measure.MUTUAL_INFORMATION_BINNED else None
+            sharded.prefetch_batch(points, prepare=prep)
         else:
             sharded.prefetch(points[0])                  # pipelined exchange: step i+1's broadcast overlaps step i
         for pi, (x, y, z) in enumerate(points):

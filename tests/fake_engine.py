@@ -28,11 +28,28 @@ class OracleEngine:
     def gather_reference_device(self, x, y, z, out, stream=0):
         out.copy_(torch.from_numpy(self.members[:, z, y, x].copy()))
 
+    def gather_reference_rows_device(self, points, out, stream=0):
+        for r, p in enumerate(points):
+            if p is None:
+                out[r].zero_()
+            else:
+                out[r].copy_(torch.from_numpy(self.members[:, p[2], p[1], p[0]].copy()))
+
+    def prepare_device(self, measure, slot, ref=None, *, device_reference=None, stream=0, **kw):
+        # the engine double "prepares" by remembering the reference vector of the slot
+        self.prepared = getattr(self, "prepared", {})
+        self.prepared[slot] = (int(measure), device_reference.numpy().copy() if device_reference is not None
+                               else self.members[:, ref[2], ref[1], ref[0]].copy())
+
     def compute_device(self, measure, out, ref=None, *, device_reference=None, stream=0, k=None,
                        kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
-                       reference_values=None):
-        refv = (device_reference.numpy().copy() if device_reference is not None
-                else self.members[:, ref[2], ref[1], ref[0]].copy())
+                       reference_values=None, prepared_slot=None):
+        if prepared_slot is not None:
+            pm, refv = self.prepared[prepared_slot]
+            assert pm == int(measure)
+        else:
+            refv = (device_reference.numpy().copy() if device_reference is not None
+                    else self.members[:, ref[2], ref[1], ref[0]].copy())
         kw = dict(k=k if k is not None else max(-(-3 * self.cs // 100), 1), estimator=kraskov_estimator_index,
                   num_bins=num_bins)
         if minmax_ref is not None:

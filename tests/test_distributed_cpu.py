@@ -63,15 +63,21 @@ def _worker(rank, world, port, zs, result_file):
                         Measure.MUTUAL_INFORMATION_KRASKOV):
             # exercise all three exchange forms: per-point prefetch(), batched prefetch_batch(), plain compute()
             pipelined = measure in (Measure.PEARSON, Measure.KENDALL)
-            batched = measure in (Measure.SPEARMAN, Measure.MUTUAL_INFORMATION_KRASKOV)
+            batched = measure == Measure.SPEARMAN
+            double_buffered = measure == Measure.MUTUAL_INFORMATION_KRASKOV   # batch i+1 exchanged before batch i is consumed
             if pipelined:
                 sharded.prefetch(points[0])
+            prep = (measure, dict(k=2)) if double_buffered else None   # + reference-side preparation ahead of time
+            if double_buffered:
+                sharded.prefetch_batch(points[0:3], prepare=prep)
             for pi, (x, y, z) in enumerate(points):
                 out = torch.empty(xs * ys * zl, dtype=torch.float32)
                 if pipelined and pi + 1 < len(points):
                     sharded.prefetch(points[pi + 1])
                 if batched and pi % 3 == 0:
                     sharded.prefetch_batch(points[pi:pi + 3])
+                if double_buffered and pi % 3 == 0 and pi + 3 < len(points):
+                    sharded.prefetch_batch(points[pi + 3:pi + 6], prepare=prep)
                 sharded.compute(measure, out, (x, y, z), k=2)
                 gathered = [torch.empty(xs * ys * slab_bounds(zs, world, r)[1], dtype=torch.float32)
                             for r in range(world)] if rank == 0 else None
@@ -92,6 +98,16 @@ def _worker(rank, world, port, zs, result_file):
                     same = (whole.view(np.uint32) == want.view(np.uint32)) | (np.isnan(whole) & np.isnan(want))
                     if not same.all():
                         failures.append((measure.name, (x, y, z), int((~same).sum())))
+        # a third outstanding batch would overwrite rows that are still pending: refused (on every rank alike)
+        sharded.prefetch_batch(points[0:1])
+        sharded.prefetch_batch(points[1:2])
+        try:
+            sharded.prefetch_batch(points[2:3])
+            failures.append("third outstanding batch was accepted")
+        except RuntimeError:
+            pass
+        for p in points[0:2]:
+            sharded.compute(Measure.PEARSON, torch.empty(xs * ys * zl, dtype=torch.float32), p)
         if rank == 0:
             Path(result_file).write_text("OK" if not failures else repr(failures))
         dist.barrier()

@@ -128,3 +128,36 @@ def test_device_synth_generator_is_slab_consistent_and_follows_the_recipe(engine
         np.testing.assert_allclose(w[c][inside], np.float32(s1[c]), rtol=1e-6)
     outside = lam == 0.0                                                              # lambda = 0: N(0,1) noise
     assert abs(w[:, outside].mean()) < 0.05 and abs(w[:, outside].std() - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("measure", list(Measure))
+@pytest.mark.parametrize("cs", [16, 50, 150])
+def test_prepared_slots_match_inline_preparation(measure, cs):
+    """crf_prepare_device + prepared_slot (two-phase evaluation of the multi-GPU driver) == the one-call evaluation."""
+    ens = synth.box_ensemble(12, 10, 6, cs, seed=cs)
+    eng = ca.CorrField(0)
+    try:
+        eng.set_grid(12, 10, 6, cs)
+        eng.upload_members(ens)
+        stream = torch.cuda.current_stream().cuda_stream
+        pts = [(1, 2, 3), (11, 9, 5), (6, 0, 0)]
+        refs = [torch.from_numpy(ens[:, z, y, x].copy()).cuda() for x, y, z in pts]
+        kw = dict(k=2, num_bins=20)
+        direct = [torch.empty(720, dtype=torch.float32, device="cuda") for _ in pts]
+        for d, r in zip(direct, refs):
+            eng.compute_device(measure, d, device_reference=r, stream=stream, **kw)
+        # prepare all three first (slots 5, 63, 0), evaluate afterwards in another order
+        for slot, r in zip((5, 63, 0), refs):
+            eng.prepare_device(measure, slot, device_reference=r, stream=stream, **kw)
+        outs = {}
+        for i in (2, 0, 1):
+            outs[i] = torch.empty(720, dtype=torch.float32, device="cuda")
+            eng.compute_device(measure, outs[i], prepared_slot=(5, 63, 0)[i], stream=stream, **kw)
+        torch.cuda.synchronize()
+        for i in range(3):
+            a, b = direct[i].cpu().numpy(), outs[i].cpu().numpy()
+            assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(), (measure, cs, i)
+        with pytest.raises(CorrFieldError):
+            eng.prepare_device(measure, 64, device_reference=refs[0], stream=stream, **kw)
+    finally:
+        eng.close()
