@@ -23,6 +23,11 @@ template <class RSRC>
 __device__ __forceinline__ float buffer_load_f32_nt(RSRC rsrc, uint32_t byte_offset) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int(byte_offset), 0, kAuxNonTemporal));
 }
+// default cache policy through the same descriptor path: for values that are read again soon (kernels that re-read
+// a voxel's members from L2 / Infinity Cache)
+__device__ __forceinline__ float load_member_cached(const float* base, uint32_t bytes, uint32_t byte_offset) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_member_rsrc(base, bytes), int(byte_offset), 0, 0));
+}
 __device__ __forceinline__ float load_member_nt(const float* base, uint32_t bytes, uint32_t byte_offset) {
     return buffer_load_f32_nt(make_member_rsrc(base, bytes), byte_offset);
 }

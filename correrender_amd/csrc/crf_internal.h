@@ -9,7 +9,7 @@ namespace crf {
 
 // Largest member count the register-resident kernels are instantiated for; above it the streaming
 // (re-reading) variants run.
-constexpr int kMaxRegisterMembers = 256;
+constexpr int kMaxRegisterMembers = 384;  // 257..384: VGPRs + AGPRs + a little scratch at one wave per SIMD
 // Largest member count supported at all by the sort-based estimators (LDS / register budgets).
 constexpr int kMaxSortMembers = 128;
 // Prepared reference-derived table: floats (see each kernels_*.hip for its layout).

@@ -101,7 +101,7 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
 }
 
 // launch_pearson pads cs to the next multiple of this: only the last granule of a guarded instantiation can be padding
-constexpr int pad_granule(int cs_pad) { return cs_pad <= 16 ? 8 : cs_pad <= 128 ? 16 : 32; }
+constexpr int pad_granule(int cs_pad) { return cs_pad <= 16 ? 8 : cs_pad <= 128 ? 16 : cs_pad <= 256 ? 32 : 64; }
 
 template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES, int BLOCK = 256, bool NT = true>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
@@ -266,6 +266,81 @@ __global__ __launch_bounds__(256) void pearson_stream_kernel(const float* const*
     out[v0] = r;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Member counts beyond the register kernels (the reference's own synthetic data set has 1000 members): the three passes
+// re-read the voxel's values, 3x the algorithmic bytes.  One wave owns 64 voxels at a time and walks the members in
+// chunks of 64 with all 64 loads of a chunk in flight; measured at 128x128x64x1000: 2.12 ms = 5.9 TB/s moved (2.0 TB/s
+// of algorithmic bytes), HBM-bound, vs 3.42 ms for the plain streaming kernel below.  A deliberately small persistent
+// grid (512-1024 waves, so that the lines of pass 1 would still be in the 256 MiB Infinity Cache for passes 2 and 3)
+// was measured too and is slower -- a wave moves only ~4 GB/s when it alternates load and compute phases, so the grid
+// must fill the chip (3.6 ms at 1024 waves, 2.3 ms at 2048, flat from 4096; profiles/tuning_r01.md).
+// Arithmetic: the same sequential fp32 passes as everywhere else.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBigWaves = 8192;  // persistent beyond this many 64-voxel tiles
+
+// One chunk = 64 members: the 64 member pointers are fetched by ONE coalesced vector load (lane l takes member e0 + l)
+// and handed to the wave one at a time with v_readlane -- no dependent scalar-load chain in front of the 64 buffer
+// loads, which all go out back to back (vmcnt allows 63 in flight).
+__device__ __forceinline__ void load_chunk_64(const float* const* __restrict__ members, int e0, int cs, uint32_t bytes,
+                                              uint32_t byte_offset, float (&buf)[64]) {
+    const int mine = e0 + int(threadIdx.x) < cs ? e0 + int(threadIdx.x) : cs - 1;
+    const uint64_t ptr = reinterpret_cast<uint64_t>(members[mine]);
+    const uint32_t ptr_lo = uint32_t(ptr), ptr_hi = uint32_t(ptr >> 32);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const uint64_t base = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_hi), i))) << 32) |
+                              uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_lo), i)));
+        buf[i] = load_member_cached(reinterpret_cast<const float*>(base), bytes,
+                                    e0 + i < cs ? byte_offset : kOutOfRangeOffset);
+    }
+}
+
+__global__ __launch_bounds__(64) void pearson_big_kernel(const float* const* __restrict__ members,
+                                                         const float* __restrict__ prep, float* __restrict__ out,
+                                                         uint32_t num_voxels, int cs) {
+    const uint32_t bytes = num_voxels * 4u;
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    const uint32_t tiles = (num_voxels + 63u) / 64u;
+#pragma unroll 1
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint32_t v0 = t * 64u + threadIdx.x;
+        const uint32_t byte_offset = v0 * 4u;  // lanes past the end read 0 and store nothing
+        float buf[64];
+        float meanY = 0.0f;
+#pragma unroll 1
+        for (int e0 = 0; e0 < cs; e0 += 64) {
+            load_chunk_64(members, e0, cs, bytes, byte_offset, buf);
+#pragma unroll
+            for (int i = 0; i < 64; i++) meanY += invN * buf[i];  // a padded slot adds invN * 0 = +0
+        }
+        float varY = 0.0f;
+#pragma unroll 1
+        for (int e0 = 0; e0 < cs; e0 += 64) {
+            load_chunk_64(members, e0, cs, bytes, byte_offset, buf);
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                const float d = e0 + i < cs ? buf[i] - meanY : 0.0f;
+                varY += invNm1 * d * d;
+            }
+        }
+        const float sdY = sqrtf(varY);
+        float r = 0.0f;
+#pragma unroll 1
+        for (int e0 = 0; e0 < cs; e0 += 64) {
+            load_chunk_64(members, e0, cs, bytes, byte_offset, buf);
+            const float a_mine = e0 + int(threadIdx.x) < cs ? prep[e0 + threadIdx.x] : 0.0f;  // a_e, one per lane
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                const float a = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(a_mine)), i)));
+                if (e0 + i < cs) r += a * ((buf[i] - meanY) / sdY);
+            }
+        }
+        if (v0 < num_voxels) out[v0] = r;
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ out, size_t n, float value) {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) out[i] = value;
@@ -364,7 +439,8 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     if (cs <= kMaxRegisterMembers) {
-        const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : (cs + 31) / 32 * 32;
+        const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : cs <= 256 ? (cs + 31) / 32 * 32
+                                                                                    : (cs + 63) / 64 * 64;
         // voxels per lane.  Measured on MI355X at 256^3 x 64 (profiles/): one voxel per lane (dword loads, 93 VGPRs,
         // 5 waves/SIMD) reaches 5.7 TB/s; 2 per lane (196 VGPRs, 2 waves/SIMD) 4.9 TB/s; 4 per lane 3.4 TB/s --
         // occupancy, not load width, is what keeps HBM busy here.  CRF_PEARSON_VPT overrides for tuning experiments.
@@ -411,12 +487,26 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
                 case 160: launch_reg_vpt<160>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 224: launch_reg_vpt<224>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
-                default: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 256: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 320: launch_reg_vpt<320>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                default: launch_reg_vpt<384>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
             }
         }
         if (info) info->kernel_name = "pearson_reg_kernel";
     } else {
-        if (info) info->kernel_name = "pearson_stream_kernel";
+        // chunked three-pass kernel (see pearson_big_kernel); CRF_PEARSON_BIG=0 selects the plain streaming kernel,
+        // CRF_PEARSON_BIG_WAVES overrides the grid (tuning)
+        if (env_int("CRF_PEARSON_BIG", 1) != 0) {
+            const size_t tiles = (num_voxels + 63) / 64;
+            const size_t want = size_t(env_int("CRF_PEARSON_BIG_WAVES", kBigWaves));
+            const unsigned blocks = unsigned(tiles < want ? tiles : want);
+            hipLaunchKernelGGL(pearson_big_kernel, dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,
+                               uint32_t(num_voxels), cs);
+            covered = num_voxels;
+            if (info) info->kernel_name = "pearson_big_kernel";
+        } else if (info) {
+            info->kernel_name = "pearson_stream_kernel";
+        }
     }
 tail:
     if (covered < num_voxels) {

@@ -22,7 +22,7 @@ def _run(engine, oracle, ens, ref_xyz):
 
 
 @pytest.mark.parametrize("cs", [2, 3, 8, 9, 16, 17, 31, 32, 33, 48, 56, 64, 65, 72, 80, 96, 100, 112, 128, 130, 150, 160,
-                                192, 200, 224, 250, 256, 300])
+                                192, 200, 224, 250, 256, 257, 300, 320, 383, 384, 385, 450, 700])
 def test_pearson_member_counts(engine, oracle, cs):
     # 20*12*9 = 2160 voxels: not a multiple of any block size -> exercises the ragged tail as well
     ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
