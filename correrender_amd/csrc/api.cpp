@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -559,6 +560,19 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
         if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || p->k > c->cs))
             return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+        if (p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) {  // O(cs) histogram kernel
+            crf::BinnedArgs ba{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
+                               p->measure == CRF_BINNED_MI_CC};
+            e = crf::launch_mi_binned_hist(c->d_member_table, c->cs, c->num_voxels, ref, ba, c->d_tables, prep, out, s, e0,
+                                           e1, &info);
+            if (e != hipErrorNotSupported) {
+                c->last_kernel = info.kernel_name ? info.kernel_name : "";
+                if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+                if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+                return CRF_OK;
+            }
+            e = hipSuccess;  // too many bins for the LDS rows: the O(cs^2) kernel below
+        }
         const size_t need = crf::generic_workspace_bytes(c->cs, c->num_voxels);
         if (need > c->workspace_bytes) {
             if (c->d_workspace) (void)hipFree(c->d_workspace);
@@ -605,6 +619,11 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("binned MI supports at most %d members", crf::kMaxSortMembers));
             crf::BinnedArgs a{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
                               p->measure == CRF_BINNED_MI_CC};
+            if (const char* hv = getenv("CRF_BINNED_HIST"); hv && *hv == '1') {  // tuning: histogram kernel for any cs
+                e = crf::launch_mi_binned_hist(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, prep, out, s,
+                                               e0, e1, &info);
+                if (e != hipErrorNotSupported) break;
+            }
             e = crf::launch_mi_binned(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, prep, out, s,
                                       e0, e1, &info);
             break;

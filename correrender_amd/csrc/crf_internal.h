@@ -84,6 +84,9 @@ struct BinnedArgs {
 hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                             const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                             hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+hipError_t launch_mi_binned_hist(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                                 const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 struct KraskovArgs {
     int k;
     int estimator;  // 1 or 2

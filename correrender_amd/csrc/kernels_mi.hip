@@ -236,6 +236,199 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Binned MI in O(cs) per voxel for ANY member count: per-lane histograms in LDS instead of a sort.
+//
+// The members are visited in the order of their reference bin b0 (binned_hist_prep_kernel sorts them once per
+// evaluation; the order and the group boundaries are voxel independent), so the samples of one reference bin -- one
+// COLUMN of the joint histogram -- are consecutive and a single per-lane row of num_bins counters, tagged with the
+// group index so that it never has to be cleared, holds the cell counts of the current column.  With T[c] = (c/cs)
+// ln(c/cs) the cell sum  sum_cells T[count]  is accumulated incrementally: raising a count from c to c+1 adds
+// T[c+1] - T[c] (telescoping).  The marginal of the voxel's own values is a second per-lane row, summed at the end.
+// Voxels with skipped samples (NaN after normalisation; total < cs, so the table does not apply) and evaluations whose
+// reference vector has invalid samples take an O(cs^2) path that re-reads the members from memory -- rare by design.
+// LDS per wave: num_bins * 64 * (2 + 4) bytes + the 8 (cs + 1)-byte difference table when it fits.
+//   prep (int32 view): [0, cs) perm: member of sorted slot e; [cs, 2cs) b0 of sorted slot e (kInvalidBin last);
+//   [2cs] 1 if every reference sample is valid; SX at kBinnedSxOffset as before.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void binned_hist_prep_kernel(RefSource src, const float* const* __restrict__ members,
+                                                               int cs, int nb, float min_ref, float max_ref,
+                                                               const double* __restrict__ tableT,
+                                                               int* __restrict__ prep) {
+    extern __shared__ int b0s[];  // cs ints
+    __shared__ int all_valid;
+    if (threadIdx.x == 0) all_valid = 1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) {
+        const float r01 = (load_ref(src, members, e) - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
+        int b = kInvalidBin;
+        if (r01 == r01) {
+            const int t = int(double(r01) * double(nb));
+            b = t < 0 ? 0 : (t > nb - 1 ? nb - 1 : t);
+        } else {
+            atomicAnd(&all_valid, 0);
+        }
+        b0s[e] = b;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cs; e += blockDim.x) {
+        const int b = b0s[e];
+        int pos = 0;
+        for (int j = 0; j < cs; j++) pos += (b0s[j] < b || (b0s[j] == b && j < e)) ? 1 : 0;  // kInvalidBin sorts last
+        prep[pos] = e;
+        prep[cs + pos] = b;
+    }
+    if (threadIdx.x == 0) {
+        double sx = 0.0;
+        for (int b = 0; b < nb; b++) {
+            int c = 0;
+            for (int e = 0; e < cs; e++) c += (b0s[e] == b);
+            sx += tableT[c];  // tableT[0] == 0
+        }
+        prep[2 * cs] = all_valid;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(prep) + kBinnedSxOffset) = sx;
+    }
+}
+
+__device__ __forceinline__ int binned_query_bin(float y, float min_q, float range_q, double nbd, int nb, bool& valid) {
+    const float q01 = (y - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
+    valid = q01 == q01;
+    int b1 = int(double(q01) * nbd);
+    return b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
+}
+
+__global__ __launch_bounds__(64) void mi_binned_hist_kernel(const float* const* __restrict__ members,
+                                                            const int* __restrict__ prep,
+                                                            const double* __restrict__ tableT, float* __restrict__ out,
+                                                            size_t num_voxels, int cs, int nb, float min_q, float max_q,
+                                                            int to_cc, int table_in_lds) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    uint32_t* hist_c = reinterpret_cast<uint32_t*>(smem) + lane;                               // [nb][64] epoch<<16 | n
+    uint16_t* hist_y = reinterpret_cast<uint16_t*>(smem + size_t(nb) * 64 * 4) + lane;         // [nb][64]
+    double* t_diff = reinterpret_cast<double*>(smem + size_t(nb) * 64 * 6);                    // [cs] T[c+1] - T[c]
+    if (table_in_lds)
+        for (int c = lane; c < cs; c += 64) t_diff[c] = tableT[c + 1] - tableT[c];
+    const int* perm = prep;
+    const int* b0s = prep + cs;
+    const bool ref_all_valid = prep[2 * cs] != 0;
+    const double sx = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(prep) + kBinnedSxOffset);
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const float range_q = max_q - min_q;
+    const double nbd = double(nb);
+    const size_t tiles = (num_voxels + 63) / 64;
+    __syncthreads();
+#pragma unroll 1
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t v = t * 64 + lane;
+        const uint32_t byte_offset = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+#pragma unroll 4
+        for (int b = 0; b < nb; b++) {
+            hist_y[b * 64] = 0;
+            hist_c[b * 64] = 0u;  // epoch 0 is never used (groups are numbered from 1)
+        }
+        bool is_nan = false;
+        int total = 0;
+        double joint = 0.0;
+        uint32_t epoch = 0u;
+        int prev_b0 = -1;
+        // chunks of 32 samples: lane l fetches the member pointer and reference bin of sample e0 + l with vector loads
+        // (one dependent chain per chunk instead of one per sample), the 32 value loads go out back to back, then the
+        // histogram updates run from registers
+#pragma unroll 1
+        for (int e0 = 0; e0 < cs; e0 += 32) {
+            const int mine = e0 + (lane & 31) < cs ? e0 + (lane & 31) : cs - 1;
+            const uint64_t ptr = reinterpret_cast<uint64_t>(members[perm[mine]]);
+            const uint32_t ptr_lo = uint32_t(ptr), ptr_hi = uint32_t(ptr >> 32);
+            const int b0_mine = b0s[mine];
+            float y[32];
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const uint64_t base = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_hi), i))) << 32) |
+                                      uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_lo), i)));
+                y[i] = load_member_nt(reinterpret_cast<const float*>(base), bytes,
+                                      e0 + i < cs ? byte_offset : kOutOfRangeOffset);
+            }
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int b0 = __builtin_amdgcn_readlane(b0_mine, i);  // wave uniform
+                const bool member = e0 + i < cs;
+                epoch += (member && b0 != prev_b0) ? 1u : 0u;
+                prev_b0 = member ? b0 : prev_b0;
+                is_nan |= member && (y[i] != y[i]);
+                bool valid;
+                const int b1 = binned_query_bin(y[i], min_q, range_q, nbd, nb, valid);
+                valid = valid && member && b0 != kInvalidBin;
+                total += valid ? 1 : 0;
+                if (valid) {
+                    const uint32_t h = hist_c[b1 * 64];
+                    const uint32_t cnt = (h >> 16) == epoch ? (h & 0xFFFFu) : 0u;
+                    joint += table_in_lds ? t_diff[cnt] : tableT[cnt + 1] - tableT[cnt];
+                    hist_c[b1 * 64] = (epoch << 16) | (cnt + 1u);
+                    hist_y[b1 * 64] = uint16_t(hist_y[b1 * 64] + 1u);
+                }
+            }
+        }
+        double mi = joint - sx;
+#pragma unroll 2
+        for (int b = 0; b < nb; b++) mi -= tableT[hist_y[b * 64]];  // tableT[0] == 0
+        const bool slow = total != cs || !ref_all_valid;
+        if (slow) {
+            // probabilities are c/total: direct evaluation, first occurrence of each bin / cell contributes its term
+            mi = 0.0;
+            if (total > 0) {
+                const double tot = double(total);
+                const double eps1 = 0.5 / double(cs);
+                const double eps2 = 0.5 / double(cs * cs);
+#pragma unroll 1
+                for (int i = 0; i < cs; i++) {
+                    bool vi;
+                    const int b1i = binned_query_bin(load_member_nt(members[perm[i]], bytes, byte_offset), min_q, range_q,
+                                                     nbd, nb, vi);
+                    const int b0i = b0s[i];
+                    if (!vi || b0i == kInvalidBin) continue;
+                    int cx = 0, cy = 0, cxy = 0;
+                    bool fx = true, fy = true, fxy = true;
+#pragma unroll 1
+                    for (int j = 0; j < cs; j++) {
+                        bool vj;
+                        const int b1j = binned_query_bin(load_member_nt(members[perm[j]], bytes, byte_offset), min_q,
+                                                         range_q, nbd, nb, vj);
+                        const int b0j = b0s[j];
+                        const bool ok = vj && b0j != kInvalidBin;
+                        const bool ex = ok && b0j == b0i;
+                        const bool ey = ok && b1j == b1i;
+                        cx += ex;
+                        cy += ey;
+                        cxy += (ex && ey);
+                        if (j < i) {
+                            fx = fx && !ex;
+                            fy = fy && !ey;
+                            fxy = fxy && !(ex && ey);
+                        }
+                    }
+                    if (fx) {
+                        const double p = double(cx) / tot;
+                        if (p > eps1) mi -= p * log(p);
+                    }
+                    if (fy) {
+                        const double p = double(cy) / tot;
+                        if (p > eps1) mi -= p * log(p);
+                    }
+                    if (fxy) {
+                        const double p = double(cxy) / tot;
+                        if (p > eps2) mi += p * log(p);
+                    }
+                }
+            }
+        }
+        float res = float(mi);
+        if (to_cc) res = mi_to_cc(res);
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (v < num_voxels) out[v] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Kraskov
 // ---------------------------------------------------------------------------------------------------------
 // prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e (MutualInformation.cpp:417-420), member order;
@@ -499,6 +692,39 @@ void launch_kraskov_prep(const RefSource& ref, const float* const* d_members, in
                          double* d_prep, hipStream_t s) {
     hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(double), s, ref, d_members, cs,
                        noise_ref, d_prep);
+}
+
+// O(cs) histogram kernel for any member count; hipErrorNotSupported when num_bins is too large for its LDS rows
+hipError_t launch_mi_binned_hist(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                                 const BinnedArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
+                                 hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    if (cs == 1) {
+        if (!ref.run()) return hipSuccess;
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        hipError_t e = launch_fill(d_out, num_voxels, 1.0f, s);
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        if (info) info->kernel_name = "fill_kernel";
+        return e;
+    }
+    const size_t rows = size_t(a.num_bins) * 64 * 6;
+    if (rows > 56 * 1024 || size_t(2 * cs + 1) * sizeof(int) > kBinnedSxOffset) return hipErrorNotSupported;
+    int* prep = reinterpret_cast<int*>(d_prep);
+    const double* tableT = d_tables + (cs + 1);
+    if (ref.prepare())
+        hipLaunchKernelGGL(binned_hist_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(int), s, ref, d_members, cs,
+                           a.num_bins, a.min_ref, a.max_ref, tableT, prep);
+    if (!ref.run()) return hipGetLastError();
+    const size_t with_table = rows + size_t(cs) * sizeof(double);
+    const bool table_in_lds = with_table <= 60 * 1024;
+    const size_t tiles = (num_voxels + 63) / 64;
+    const unsigned blocks = unsigned(tiles < 16384 ? tiles : 16384);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    hipLaunchKernelGGL(mi_binned_hist_kernel, dim3(blocks), dim3(64), table_in_lds ? with_table : rows, s, d_members, prep,
+                       tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc),
+                       int(table_in_lds));
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "mi_binned_hist_kernel";
+    return hipGetLastError();
 }
 
 hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
