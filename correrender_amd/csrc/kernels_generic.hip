@@ -26,10 +26,14 @@ constexpr size_t kLdsTileLimit = 60 * 1024;  // use LDS for the tile when it fit
 __host__ __device__ inline size_t tile_bytes(int cs) { return size_t(cs) * 64 * (sizeof(float) + sizeof(uint16_t)); }
 }  // namespace
 
+size_t direct_rank_workspace_bytes(int cs, size_t num_voxels, int measure);
+
 size_t generic_workspace_bytes(int cs, size_t num_voxels) {
     if (tile_bytes(cs) <= kLdsTileLimit) return 0;
     const size_t tiles = (num_voxels + 63) / 64;
-    return tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+    const size_t generic = tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+    const size_t direct = direct_rank_workspace_bytes(cs, num_voxels, 1);
+    return generic > direct ? generic : direct;
 }
 
 __device__ __forceinline__ float mi_to_cc_generic(float mi);  // defined below (same map as kernels_mi.hip)
@@ -38,16 +42,27 @@ __device__ __forceinline__ float mi_to_cc_generic(float mi);  // defined below (
 
 // Spearman: ranks by counting, then computePearson2<float>(referenceRanks, ranks, cs) in member order.
 __device__ float spearman_voxel(const float* vals, uint16_t* aux, const float* __restrict__ prep_a, int cs) {
+    // register blocking: 8 members are ranked per sweep over the column, so every value read from the tile (LDS or the
+    // L2-resident workspace) serves 8 comparisons
+    constexpr int TE = 8;
 #pragma unroll 1
-    for (int e = 0; e < cs; e++) {
-        const float ve = vals[e * 64];
-        uint32_t s = 0;
-#pragma unroll 4
+    for (int e0 = 0; e0 < cs; e0 += TE) {
+        float ve[TE];
+        uint32_t sc[TE];
+#pragma unroll
+        for (int t = 0; t < TE; t++) {
+            ve[t] = vals[(e0 + t < cs ? e0 + t : cs - 1) * 64];
+            sc[t] = 0u;
+        }
+#pragma unroll 2
         for (int j = 0; j < cs; j++) {
             const float vj = vals[j * 64];
-            s += (vj < ve) ? 2u : ((vj == ve) ? 1u : 0u);
+#pragma unroll
+            for (int t = 0; t < TE; t++) sc[t] += (vj < ve[t]) ? 2u : ((vj == ve[t]) ? 1u : 0u);
         }
-        aux[e * 64] = uint16_t(s + 1u);  // 2 * rank (self contributes the +1 of [v_e == v_e])
+#pragma unroll
+        for (int t = 0; t < TE; t++)
+            if (e0 + t < cs) aux[(e0 + t) * 64] = uint16_t(sc[t] + 1u);  // 2 * rank (self contributes the +1 of [v_e == v_e])
     }
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -72,17 +87,28 @@ __device__ float spearman_voxel(const float* vals, uint16_t* aux, const float* _
 __device__ float kendall_voxel(const float* vals, const int* __restrict__ prep, int cs) {
     const int* gend = prep + cs;  // slot -> last slot of its x-tie group
     int32_t discordant = 0, n2 = 0;
+    // register blocking over i (8 rows per sweep).  For row i the sweep covers j > i: ties in y count for every such j,
+    // discordance only for j beyond the row's x-tie group (j > gend[i]).
+    constexpr int TI = 8;
 #pragma unroll 1
-    for (int i = 0; i < cs; i++) {
-        const float yi = vals[i * 64];
-        const int g = gend[i];
-#pragma unroll 1
-        for (int j = i + 1; j <= g; j++) n2 += (vals[j * 64] == yi) ? 1 : 0;  // same x: ties in y only
-#pragma unroll 4
-        for (int j = g + 1; j < cs; j++) {
+    for (int i0 = 0; i0 < cs; i0 += TI) {
+        float yi[TI];
+        int gi[TI];
+#pragma unroll
+        for (int t = 0; t < TI; t++) {
+            const int i = i0 + t < cs ? i0 + t : cs - 1;
+            yi[t] = vals[i * 64];
+            gi[t] = i0 + t < cs ? gend[i] : cs;  // rows past the end: nothing counts (j > cs never holds)
+        }
+#pragma unroll 2
+        for (int j = i0 + 1; j < cs; j++) {
             const float yj = vals[j * 64];
-            n2 += (yj == yi) ? 1 : 0;
-            discordant += (yi > yj) ? 1 : 0;
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                const bool after = j > i0 + t && i0 + t < cs;
+                n2 += (after && yj == yi[t]) ? 1 : 0;
+                discordant += (after && j > gi[t] && yi[t] > yj) ? 1 : 0;
+            }
         }
     }
     const int32_t n = cs;
@@ -224,6 +250,116 @@ __device__ float kraskov_voxel(const float* vals, const double* __restrict__ px,
     const double mi = -sum_x - sum_y + c + psi[cs];
     const float res = float(mi);
     return (res < 0.0f) ? 0.0f : res;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spearman / Kendall for member counts whose voxel tile does not fit LDS (cs > 160): the O(cs^2) sweeps read the
+// values straight from the member volumes (a wave's read of one member is the same coalesced 256 B as a read of a
+// workspace copy would be, and with 16 rows per sweep there are 16 comparisons per value read), so no per-block copy of
+// the values exists, the grid is not limited by workspace size (the old scheme ran one wave per SIMD) and only
+// Spearman keeps a per-voxel column: the 16-bit doubled ranks, in a global workspace slice per block.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDirectBlocks = 4096;
+constexpr int kDirectRows = 16;
+
+size_t direct_rank_workspace_bytes(int cs, size_t num_voxels, int measure) {
+    if (measure != 1) return 0;
+    const size_t tiles = (num_voxels + 63) / 64;
+    return size_t(cs) * 64 * sizeof(uint16_t) * (tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
+}
+
+// measure 1: Spearman (prep = float a_e), 2: Kendall (prep = int perm / gend / n1 with stride cs)
+__global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __restrict__ members,
+                                                         const void* __restrict__ prep, float* __restrict__ out,
+                                                         size_t num_voxels, int cs, int measure,
+                                                         uint16_t* __restrict__ workspace) {
+    constexpr int T = kDirectRows;
+    const int lane = threadIdx.x;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const int* prep_i = static_cast<const int*>(prep);
+    const float* prep_a = static_cast<const float*>(prep);
+    uint16_t* aux = workspace ? workspace + size_t(blockIdx.x) * size_t(cs) * 64 + lane : nullptr;
+    const size_t tiles = (num_voxels + 63) / 64;
+#pragma unroll 1
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t v = t * 64 + lane;
+        const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+        float res;
+        bool is_nan = false;
+        if (measure == 1) {
+#pragma unroll 1
+            for (int e0 = 0; e0 < cs; e0 += T) {
+                float ve[T];
+                uint32_t sc[T];
+#pragma unroll
+                for (int r = 0; r < T; r++) {
+                    ve[r] = load_member_cached(members[e0 + r < cs ? e0 + r : cs - 1], bytes, off);
+                    is_nan |= ve[r] != ve[r];
+                    sc[r] = 0u;
+                }
+#pragma unroll 4
+                for (int j = 0; j < cs; j++) {
+                    const float vj = load_member_cached(members[j], bytes, off);
+#pragma unroll
+                    for (int r = 0; r < T; r++) sc[r] += (vj < ve[r]) ? 2u : ((vj == ve[r]) ? 1u : 0u);
+                }
+#pragma unroll
+                for (int r = 0; r < T; r++)
+                    if (e0 + r < cs) aux[size_t(e0 + r) * 64] = uint16_t(sc[r] + 1u);  // 2 * rank
+            }
+            // computePearson2<float>(referenceRanks, ranks, cs) in member order
+            const float n = float(cs);
+            const float invN = 1.0f / n;
+            const float invNm1 = 1.0f / (n - 1.0f);
+            float meanY = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) meanY += invN * (0.5f * float(aux[size_t(e) * 64]));
+            float varY = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) {
+                const float d = 0.5f * float(aux[size_t(e) * 64]) - meanY;
+                varY += invNm1 * d * d;
+            }
+            const float sdY = sqrtf(varY);
+            float r = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) r += prep_a[e] * ((0.5f * float(aux[size_t(e) * 64]) - meanY) / sdY);
+            res = r;
+        } else {
+            const int* gend = prep_i + cs;  // slot -> last slot of its x-tie group (slots = reference-sorted order)
+            int32_t discordant = 0, n2 = 0;
+#pragma unroll 1
+            for (int i0 = 0; i0 < cs; i0 += T) {
+                float yi[T];
+                int gi[T];
+#pragma unroll
+                for (int r = 0; r < T; r++) {
+                    const int i = i0 + r < cs ? i0 + r : cs - 1;
+                    yi[r] = load_member_cached(members[prep_i[i]], bytes, off);
+                    is_nan |= yi[r] != yi[r];
+                    gi[r] = i0 + r < cs ? gend[i] : cs;
+                }
+#pragma unroll 2
+                for (int j = i0 + 1; j < cs; j++) {
+                    const float yj = load_member_cached(members[prep_i[j]], bytes, off);
+#pragma unroll
+                    for (int r = 0; r < T; r++) {
+                        const bool after = j > i0 + r && i0 + r < cs;
+                        n2 += (after && yj == yi[r]) ? 1 : 0;
+                        discordant += (after && j > gi[r] && yi[r] > yj) ? 1 : 0;
+                    }
+                }
+            }
+            const int32_t n = cs;
+            const int32_t n0 = (n * (n - 1)) / 2;
+            const int32_t n1 = prep_i[2 * cs];
+            const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
+            const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2));
+            res = float(numerator) / denominator;
+        }
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (v < num_voxels) out[v] = res;
+    }
 }
 
 __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restrict__ members,
@@ -568,6 +704,16 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
     }
     if (!ref.run()) return hipGetLastError();
     const size_t tiles = (num_voxels + 63) / 64;
+    if ((a.measure == 1 || a.measure == 2) && tile_bytes(cs) > kLdsTileLimit) {
+        const unsigned dblocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
+        if (a.measure == 1 && !d_workspace) return hipErrorInvalidValue;
+        if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        hipLaunchKernelGGL(direct_rank_kernel, dim3(dblocks), dim3(64), 0, s, d_members, static_cast<const void*>(d_prep),
+                           d_out, num_voxels, cs, a.measure, reinterpret_cast<uint16_t*>(d_workspace));
+        if (ev_end) (void)hipEventRecord(ev_end, s);
+        if (info) info->kernel_name = "direct_rank_kernel";
+        return hipGetLastError();
+    }
     const unsigned blocks = unsigned(tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
     const bool use_lds = tile_bytes(cs) <= kLdsTileLimit;
     if (!use_lds && !d_workspace) return hipErrorInvalidValue;
