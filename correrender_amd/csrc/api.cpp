@@ -573,6 +573,18 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             }
             e = hipSuccess;  // too many bins for the LDS rows: the O(cs^2) kernel below
         }
+        if (p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) {  // tile-free single-sweep top-K kernel
+            crf::KraskovArgs ka{p->k, p->kraskov_estimator_index == 2 ? 2 : 1, p->measure == CRF_KMI_CC};
+            e = crf::launch_mi_kraskov_direct(c->d_member_table, c->cs, c->num_voxels, ref, ka, c->d_tables, prep, out, s,
+                                              e0, e1, &info);
+            if (e != hipErrorNotSupported) {
+                c->last_kernel = info.kernel_name ? info.kernel_name : "";
+                if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
+                if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
+                return CRF_OK;
+            }
+            e = hipSuccess;  // k > 128 or tables beyond LDS: the repeated-minimum kernel below
+        }
         const size_t need = crf::generic_workspace_bytes(c->cs, c->num_voxels);
         if (need > c->workspace_bytes) {
             if (c->d_workspace) (void)hipFree(c->d_workspace);

@@ -96,6 +96,10 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
+hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                                    const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out,
+                                    hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
+
 // ---- kernels_generic.hip: any member count (O(cs^2) counting algorithms, runtime loops) ------------------
 struct GenericArgs {
     int measure;  // crf_measure value

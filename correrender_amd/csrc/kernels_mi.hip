@@ -659,6 +659,168 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
     if (v < num_voxels) out[v] = res;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Kraskov for any member count and any k <= 128: no per-voxel tile at all.  A lane keeps, for TI points at a time, the
+// K >= k smallest distances in registers (sorted insertion, 2K min/max per candidate) while it sweeps the members
+// straight from the member volumes (coalesced 256 B per wave and member, as a tile read would be); the marginal counts
+// take a second sweep.  One sweep per TI points instead of the k sweeps per point of the repeated-minimum selection:
+// at 1000 members and k = 30 that is ~60x fewer distance evaluations.  LDS holds the voxel-independent tables only.
+// ---------------------------------------------------------------------------------------------------------------
+// Blocks of 4 waves share one copy of the tables in LDS (24 KB at 1000 members: with one wave per block LDS would cap
+// the occupancy at 1.5 waves per SIMD).
+template <int K, int TI>
+__global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const* __restrict__ members,
+                                                            const double* __restrict__ prep_px,
+                                                            const double* __restrict__ table_psi,
+                                                            const double* __restrict__ noise_query,
+                                                            float* __restrict__ out, size_t num_voxels, int cs, int k,
+                                                            int estimator, int to_cc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* s_px = reinterpret_cast<double*>(smem);  // member order
+    double* s_spx = s_px + cs;                       // ascending
+    double* s_nq = s_spx + cs;
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < cs; i += 256) {
+        s_px[i] = prep_px[i];
+        s_spx[i] = prep_px[cs + i];
+        s_nq[i] = noise_query[i];
+    }
+    __syncthreads();
+    constexpr int JB = 16;  // member values fetched per batch of the sweeps
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const int kk = k < cs - 1 ? k : cs - 1;
+    int top = 1;
+    while (top * 2 <= cs) top *= 2;
+    const double factor = 1.0 / double(cs);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const size_t tiles = (num_voxels + 63) / 64;
+#pragma unroll 1
+    for (size_t tile = size_t(blockIdx.x) * 4 + (threadIdx.x >> 6); tile < tiles; tile += size_t(gridDim.x) * 4) {
+        const size_t v = tile * 64 + lane;
+        const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+        bool is_nan = false;
+        double sum_x = 0.0, sum_y = 0.0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < cs; i0 += TI) {
+            double pxi[TI], pyi[TI], dk[TI], rx[TI], ry[TI];
+            double best[TI][K];
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
+                const float y = load_member_cached(members[ii], bytes, off);
+                is_nan |= y != y;
+                pxi[t] = s_px[ii];
+                pyi[t] = double(y) + s_nq[ii];
+#pragma unroll
+                for (int q = 0; q < K; q++) best[t][q] = inf;
+            }
+            // ---- sweep A: the K smallest Chebyshev distances to OTHER points (MutualInformation.cpp:430-434)
+            //      (the member values come in batches of JB loads issued back to back: one memory latency per batch)
+#pragma unroll 1
+            for (int j0 = 0; j0 < cs; j0 += JB) {
+                float yb[JB];
+#pragma unroll
+                for (int u = 0; u < JB; u++)
+                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+#pragma unroll
+                for (int u = 0; u < JB; u++) {
+                    const int j = j0 + u;
+                    const int jc = j < cs ? j : cs - 1;
+                    const double pxj = s_px[jc];
+                    const double pyj = double(yb[u]) + s_nq[jc];
+#pragma unroll
+                    for (int t = 0; t < TI; t++) {
+                        double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
+                        d = (j == i0 + t || j >= cs) ? inf : d;
+#pragma unroll
+                        for (int q = 0; q < K; q++) {
+                            const double lo = min_f64(best[t][q], d);
+                            if (q + 1 < K) d = max_f64(best[t][q], d);
+                            best[t][q] = lo;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                double sel = best[t][0];
+#pragma unroll
+                for (int q = 1; q < K; q++) sel = (q == kk - 1) ? best[t][q] : sel;
+                dk[t] = sel;
+            }
+            if (estimator == 1) {
+#pragma unroll
+                for (int t = 0; t < TI; t++) rx[t] = ry[t] = dk[t] - kCountSlack;  // includeCenter, :196-197
+            } else {
+                double ex[TI], ey[TI];
+#pragma unroll
+                for (int t = 0; t < TI; t++) ex[t] = ey[t] = 0.0;
+#pragma unroll 2
+                for (int j = 0; j < cs; j++) {
+                    const double pxj = s_px[j];
+                    const double pyj = double(load_member_cached(members[j], bytes, off)) + s_nq[j];
+#pragma unroll
+                    for (int t = 0; t < TI; t++) {
+                        const double ax = fabs(pxi[t] - pxj), ay = fabs(pyi[t] - pyj);
+                        const bool in = fmax(ax, ay) <= dk[t];
+                        ex[t] = in ? fmax(ex[t], ax) : ex[t];
+                        ey[t] = in ? fmax(ey[t], ay) : ey[t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TI; t++) {
+                    rx[t] = ex[t] + kCountSlack;
+                    ry[t] = ey[t] + kCountSlack;
+                }
+            }
+            // ---- sweep C: marginal counts (:201-233)
+            double loy[TI], hiy[TI];
+            int cx[TI], cy[TI];
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                cx[t] = count_less(s_spx, cs, top, pxi[t] + rx[t]) - count_less(s_spx, cs, top, pxi[t] - rx[t]);
+                loy[t] = pyi[t] - ry[t];
+                hiy[t] = pyi[t] + ry[t];
+                cy[t] = 0;
+            }
+#pragma unroll 1
+            for (int j0 = 0; j0 < cs; j0 += JB) {
+                float yb[JB];
+#pragma unroll
+                for (int u = 0; u < JB; u++)
+                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+#pragma unroll
+                for (int u = 0; u < JB; u++) {
+                    const double pyj = double(yb[u]) + s_nq[j0 + u < cs ? j0 + u : cs - 1];
+#pragma unroll
+                    for (int t = 0; t < TI; t++) cy[t] += (j0 + u < cs && pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                if (i0 + t < cs) {
+                    int nx = cx[t] > 1 ? cx[t] : 1;
+                    int ny = cy[t] > 1 ? cy[t] : 1;
+                    if (estimator != 1) {
+                        nx -= 1;  // psi(n - 1), psi(0) = NaN (pole)
+                        ny -= 1;
+                    }
+                    sum_x += factor * table_psi[nx];
+                    sum_y += factor * table_psi[ny];
+                }
+            }
+        }
+        double c = table_psi[k <= cs ? k : cs];
+        if (estimator != 1) c -= 1.0 / double(k);
+        const double mi = -sum_x - sum_y + c + table_psi[cs];
+        float res = float(mi);
+        res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
+        if (to_cc) res = mi_to_cc(res);
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (v < num_voxels) out[v] = res;
+    }
+}
+
 namespace {
 
 template <int N, int MIN_WAVES>
@@ -773,6 +935,45 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     return hipGetLastError();
 }
 
+// any cs (tables must fit LDS: cs <= 2048), k <= 128; hipErrorNotSupported otherwise
+hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                                    const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out,
+                                    hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    const int kk = a.k < cs - 1 ? a.k : cs - 1;
+    const size_t lds = size_t(3 * cs) * sizeof(double);
+    if (kk > 128 || lds > 60 * 1024) return hipErrorNotSupported;
+    const double* psi = d_tables;
+    const double* noise_ref = d_tables + 2 * (cs + 1);
+    const double* noise_query = noise_ref + cs;
+    double* prep = reinterpret_cast<double*>(d_prep);
+    if (ref.prepare()) launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
+    if (!ref.run()) return hipGetLastError();
+    const size_t tiles = (num_voxels + 63) / 64;
+    const size_t groups = (tiles + 3) / 4;
+    const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+#define CRF_LAUNCH_DIRECT(K, TI)                                                                                    \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, prep, psi,        \
+                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
+    if (kk <= 4) {
+        CRF_LAUNCH_DIRECT(4, 8);
+    } else if (kk <= 8) {
+        CRF_LAUNCH_DIRECT(8, 4);
+    } else if (kk <= 16) {
+        CRF_LAUNCH_DIRECT(16, 2);
+    } else if (kk <= 32) {
+        CRF_LAUNCH_DIRECT(32, 1);
+    } else if (kk <= 64) {
+        CRF_LAUNCH_DIRECT(64, 1);
+    } else {
+        CRF_LAUNCH_DIRECT(128, 1);
+    }
+#undef CRF_LAUNCH_DIRECT
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "kraskov_direct_kernel";
+    return hipGetLastError();
+}
+
 hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
                              hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
@@ -784,6 +985,16 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
         if (info) info->kernel_name = "fill_kernel";
         return e;
     }
+    const int kk = a.k < cs - 1 ? a.k : cs - 1;
+    const char* force_direct = getenv("CRF_KRASKOV_DIRECT");  // tuning: the tile-free kernel for every k
+    // The LDS-tile kernels below are instantiated for k <= 4 and hold a 256*cs-byte column per wave, which caps the
+    // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
+    // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
+    if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1')) {
+        hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
+                                                ev_end, info);
+        if (e != hipErrorNotSupported) return e;
+    }
     const double* psi = d_tables;
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
@@ -792,7 +1003,6 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     if (!ref.run()) return hipGetLastError();
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
-    const int kk = a.k < cs - 1 ? a.k : cs - 1;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
 #define CRF_LAUNCH_KRASKOV(K, TI)                                                                                     \
     hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \

@@ -94,7 +94,8 @@ def test_binned_partial_skips_with_infinities(engine, oracle):
 
 
 @pytest.mark.parametrize("cs,k", [(8, 1), (16, 1), (16, 3), (33, 2), (64, 2), (64, 3), (64, 4), (100, 3), (128, 4),
-                                  (64, 6), (40, 12)])
+                                  (64, 5), (64, 6), (40, 12), (64, 8), (64, 9), (64, 16), (64, 17), (64, 20), (100, 32),
+                                  (100, 33), (128, 64), (100, 65), (160, 128), (40, 39), (40, 40)])
 def test_kraskov_ksg1(engine, oracle, cs, k):
     ens = synth.normal_ensemble(16, 8, 6, cs, seed=300 + cs)      # tie-free: independent of the noise stream
     ens[:, 0, 0, 1] = 0.8 * ens[:, 0, 0, 0] + 0.6 * ens[:, 0, 0, 1]   # a dependent voxel
@@ -103,7 +104,7 @@ def test_kraskov_ksg1(engine, oracle, cs, k):
     assert (got >= 0).all()        # clamped at 0 (MutualInformation.cpp:443)
 
 
-@pytest.mark.parametrize("cs,k", [(16, 2), (64, 3), (100, 5)])
+@pytest.mark.parametrize("cs,k", [(16, 2), (64, 3), (100, 5), (64, 12), (100, 40), (160, 70)])
 def test_kraskov_ksg2(engine, oracle, cs, k):
     ens = synth.normal_ensemble(16, 8, 6, cs, seed=400 + cs)
     _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV, f"KSG-2 cs={cs} k={k}",
