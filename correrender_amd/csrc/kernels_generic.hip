@@ -29,10 +29,11 @@ __host__ __device__ inline size_t tile_bytes(int cs) { return size_t(cs) * 64 * 
 size_t direct_rank_workspace_bytes(int cs, size_t num_voxels, int measure);
 
 size_t generic_workspace_bytes(int cs, size_t num_voxels) {
-    if (tile_bytes(cs) <= kLdsTileLimit) return 0;
     const size_t tiles = (num_voxels + 63) / 64;
-    const size_t generic = tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
-    const size_t direct = direct_rank_workspace_bytes(cs, num_voxels, 1);
+    const size_t generic = tile_bytes(cs) <= kLdsTileLimit
+                               ? 0
+                               : tile_bytes(cs) * (tiles < size_t(kGenericBlocks) ? tiles : size_t(kGenericBlocks));
+    const size_t direct = direct_rank_workspace_bytes(cs, num_voxels, 1);  // Spearman's doubled ranks
     return generic > direct ? generic : direct;
 }
 
@@ -253,7 +254,8 @@ __device__ float kraskov_voxel(const float* vals, const double* __restrict__ px,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Spearman / Kendall for member counts whose voxel tile does not fit LDS (cs > 160): the O(cs^2) sweeps read the
+// Spearman / Kendall beyond the register kernels (cs > 128; the LDS-tile kernel above measured 3.8x slower at 130
+// members because a 50 KB tile per wave leaves one wave per SIMD): the O(cs^2) sweeps read the
 // values straight from the member volumes (a wave's read of one member is the same coalesced 256 B as a read of a
 // workspace copy would be, and with 16 rows per sweep there are 16 comparisons per value read), so no per-block copy of
 // the values exists, the grid is not limited by workspace size (the old scheme ran one wave per SIMD) and only
@@ -704,7 +706,9 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
     }
     if (!ref.run()) return hipGetLastError();
     const size_t tiles = (num_voxels + 63) / 64;
-    if ((a.measure == 1 || a.measure == 2) && tile_bytes(cs) > kLdsTileLimit) {
+    const char* force_tile = getenv("CRF_RANK_TILE");  // tuning: keep the LDS-tile kernel wherever the tile fits
+    if ((a.measure == 1 || a.measure == 2) &&
+        (tile_bytes(cs) > kLdsTileLimit || !(force_tile && *force_tile == '1'))) {
         const unsigned dblocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
         if (a.measure == 1 && !d_workspace) return hipErrorInvalidValue;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
