@@ -435,6 +435,12 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
         e = crf::launch_pearson_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, out, s);
         c->last_kernel = "pearson_symmetric_kernel";
     }
+    if (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL) {
+        if (int r = ensure_workspace(c, crf::direct_symmetric_workspace_bytes(c->cs, c->num_voxels, p->measure))) return r;
+        e = crf::launch_direct_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->measure,
+                                         c->d_workspace, out, s);
+        c->last_kernel = "direct_symmetric_kernel";
+    }
     if (e == hipErrorNotSupported) {
         if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, c->num_voxels))) return r;
         const crf::PairArgs a{p->measure, p->num_bins, p->k, 0, 1, p->min_ref, p->max_ref, p->min_query, p->max_query};

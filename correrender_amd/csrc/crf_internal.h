@@ -138,6 +138,11 @@ size_t pair_workspace_bytes(int cs, size_t num_requests);
 hipError_t launch_pair_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
                                 size_t num_voxels, const uint32_t* d_requests, size_t num_requests, const PairArgs& a,
                                 const double* d_tables, unsigned char* d_workspace, float* d_out, hipStream_t s);
+// symmetric field mode, Spearman (measure 1) / Kendall (2), any member count (kernels_generic.hip)
+size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure);
+hipError_t launch_direct_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                   size_t num_voxels, int measure, unsigned char* d_workspace, float* d_out,
+                                   hipStream_t s);
 // symmetric field mode, Pearson, members resident in registers (kernels_pearson.hip); hipErrorNotSupported above
 // kMaxSymmetricRegisterMembers (the caller then uses launch_pair_requests)
 constexpr int kMaxSymmetricRegisterMembers = 128;

@@ -364,6 +364,134 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric field mode (CRF_FLAG_SYMMETRIC), Spearman and Kendall, any member count: both vectors of a voxel are voxel
+// dependent, so nothing is prepared; same direct-read scheme as direct_rank_kernel with two member tables.
+//   Spearman: doubled ranks of X and of Y by counting (two 16-bit columns per voxel in the block's workspace slice),
+//             then computePearson2<float> on the two rank vectors in member order.
+//   Kendall : tau-b in pair form -- S_y = #{x_a < x_b, y_a > y_b}, n1 = #{x_a == x_b}, n2 = #{y_a == y_b} over
+//             unordered pairs (the sort of computeKendall orders equal x by y, so x-tied pairs add no inversion;
+//             Correlation.cpp:423-455).
+// ---------------------------------------------------------------------------------------------------------------
+size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure) {
+    if (measure != 1) return 0;
+    const size_t tiles = (num_voxels + 63) / 64;
+    return size_t(cs) * 64 * 2 * sizeof(uint16_t) * (tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
+}
+
+__global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const* __restrict__ members_x,
+                                                              const float* const* __restrict__ members_y,
+                                                              float* __restrict__ out, size_t num_voxels, int cs,
+                                                              int measure, uint16_t* __restrict__ workspace) {
+    constexpr int T = kDirectRows;
+    const int lane = threadIdx.x;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    uint16_t* rx = workspace ? workspace + size_t(blockIdx.x) * size_t(cs) * 128 + lane : nullptr;
+    uint16_t* ry = rx ? rx + size_t(cs) * 64 : nullptr;
+    const size_t tiles = (num_voxels + 63) / 64;
+#pragma unroll 1
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t v = t * 64 + lane;
+        const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+        float res;
+        bool is_nan = false;
+        if (measure == 1) {
+#pragma unroll 1
+            for (int side = 0; side < 2; side++) {
+                const float* const* __restrict__ m = side == 0 ? members_x : members_y;
+                uint16_t* r2 = side == 0 ? rx : ry;
+#pragma unroll 1
+                for (int e0 = 0; e0 < cs; e0 += T) {
+                    float ve[T];
+                    uint32_t sc[T];
+#pragma unroll
+                    for (int r = 0; r < T; r++) {
+                        ve[r] = load_member_cached(m[e0 + r < cs ? e0 + r : cs - 1], bytes, off);
+                        is_nan |= ve[r] != ve[r];
+                        sc[r] = 0u;
+                    }
+#pragma unroll 4
+                    for (int j = 0; j < cs; j++) {
+                        const float vj = load_member_cached(m[j], bytes, off);
+#pragma unroll
+                        for (int r = 0; r < T; r++) sc[r] += (vj < ve[r]) ? 2u : ((vj == ve[r]) ? 1u : 0u);
+                    }
+#pragma unroll
+                    for (int r = 0; r < T; r++)
+                        if (e0 + r < cs) r2[size_t(e0 + r) * 64] = uint16_t(sc[r] + 1u);
+                }
+            }
+            const float n = float(cs);
+            const float invN = 1.0f / n;
+            const float invNm1 = 1.0f / (n - 1.0f);
+            float meanX = 0.0f, meanY = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) {
+                meanX += invN * (0.5f * float(rx[size_t(e) * 64]));
+                meanY += invN * (0.5f * float(ry[size_t(e) * 64]));
+            }
+            float varX = 0.0f, varY = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) {
+                const float dx = 0.5f * float(rx[size_t(e) * 64]) - meanX, dy = 0.5f * float(ry[size_t(e) * 64]) - meanY;
+                varX += invNm1 * dx * dx;
+                varY += invNm1 * dy * dy;
+            }
+            const float sdX = sqrtf(varX), sdY = sqrtf(varY);
+            float r = 0.0f;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++)
+                r += invNm1 * ((0.5f * float(rx[size_t(e) * 64]) - meanX) / sdX) *
+                     ((0.5f * float(ry[size_t(e) * 64]) - meanY) / sdY);
+            res = r;
+        } else {
+            int32_t discordant = 0, n1 = 0, n2 = 0;
+#pragma unroll 1
+            for (int i0 = 0; i0 < cs; i0 += T) {
+                float xi[T], yi[T];
+#pragma unroll
+                for (int r = 0; r < T; r++) {
+                    const int i = i0 + r < cs ? i0 + r : cs - 1;
+                    xi[r] = load_member_cached(members_x[i], bytes, off);
+                    yi[r] = load_member_cached(members_y[i], bytes, off);
+                    is_nan |= xi[r] != xi[r] || yi[r] != yi[r];
+                }
+#pragma unroll 2
+                for (int j = i0 + 1; j < cs; j++) {
+                    const float xj = load_member_cached(members_x[j], bytes, off);
+                    const float yj = load_member_cached(members_y[j], bytes, off);
+#pragma unroll
+                    for (int r = 0; r < T; r++) {
+                        const bool after = j > i0 + r && i0 + r < cs;
+                        n1 += (after && xi[r] == xj) ? 1 : 0;
+                        n2 += (after && yi[r] == yj) ? 1 : 0;
+                        discordant += (after && ((xi[r] < xj && yi[r] > yj) || (xj < xi[r] && yj > yi[r]))) ? 1 : 0;
+                    }
+                }
+            }
+            const int32_t n = cs;
+            const int32_t n0 = (n * (n - 1)) / 2;
+            const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
+            res = float(numerator) / (sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2)));
+        }
+        if (is_nan) res = __uint_as_float(0x7FC00000u);
+        if (cs == 1) res = 1.0f;
+        if (v < num_voxels) out[v] = res;
+    }
+}
+
+hipError_t launch_direct_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                   size_t num_voxels, int measure, unsigned char* d_workspace, float* d_out,
+                                   hipStream_t s) {
+    if (measure != 1 && measure != 2) return hipErrorNotSupported;
+    if (measure == 1 && !d_workspace) return hipErrorInvalidValue;
+    const size_t tiles = (num_voxels + 63) / 64;
+    const unsigned blocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
+    hipLaunchKernelGGL(direct_symmetric_kernel, dim3(blocks), dim3(64), 0, s, d_members_x, d_members_y, d_out, num_voxels,
+                       cs, measure, reinterpret_cast<uint16_t*>(d_workspace));
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restrict__ members,
                                                      const void* __restrict__ prep, const double* __restrict__ tables,
                                                      float* __restrict__ out, size_t num_voxels, int cs, GenericArgs a,
