@@ -435,10 +435,17 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
         e = crf::launch_pearson_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, out, s);
         c->last_kernel = "pearson_symmetric_kernel";
     }
-    if (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL) {
+    if (p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) {
+        e = crf::launch_mi_kraskov_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->k,
+                                             p->measure == CRF_KMI_CC, c->d_tables, out, s);
+        c->last_kernel = "kraskov_direct_kernel";
+    }
+    if (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL || p->measure == CRF_MI_BINNED ||
+        p->measure == CRF_BINNED_MI_CC) {
         if (int r = ensure_workspace(c, crf::direct_symmetric_workspace_bytes(c->cs, c->num_voxels, p->measure))) return r;
-        e = crf::launch_direct_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->measure,
-                                         c->d_workspace, out, s);
+        e = crf::launch_direct_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->measure, p->num_bins,
+                                         p->min_ref, p->max_ref, p->min_query, p->max_query, c->d_tables, c->d_workspace,
+                                         out, s);
         c->last_kernel = "direct_symmetric_kernel";
     }
     if (e == hipErrorNotSupported) {

@@ -100,6 +100,10 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
                                     const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out,
                                     hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
+hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                       size_t num_voxels, int k, bool to_cc, const double* d_tables, float* d_out,
+                                       hipStream_t s);
+
 // ---- kernels_generic.hip: any member count (O(cs^2) counting algorithms, runtime loops) ------------------
 struct GenericArgs {
     int measure;  // crf_measure value
@@ -138,10 +142,11 @@ size_t pair_workspace_bytes(int cs, size_t num_requests);
 hipError_t launch_pair_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
                                 size_t num_voxels, const uint32_t* d_requests, size_t num_requests, const PairArgs& a,
                                 const double* d_tables, unsigned char* d_workspace, float* d_out, hipStream_t s);
-// symmetric field mode, Spearman (measure 1) / Kendall (2), any member count (kernels_generic.hip)
+// symmetric field mode, Spearman (measure 1) / Kendall (2) / binned MI (3, 5), any member count (kernels_generic.hip)
 size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure);
 hipError_t launch_direct_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
-                                   size_t num_voxels, int measure, unsigned char* d_workspace, float* d_out,
+                                   size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
+                                   float max_y, const double* d_tables, unsigned char* d_workspace, float* d_out,
                                    hipStream_t s);
 // symmetric field mode, Pearson, members resident in registers (kernels_pearson.hip); hipErrorNotSupported above
 // kMaxSymmetricRegisterMembers (the caller then uses launch_pair_requests)

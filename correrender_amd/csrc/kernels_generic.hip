@@ -374,15 +374,26 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
 //             Correlation.cpp:423-455).
 // ---------------------------------------------------------------------------------------------------------------
 size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure) {
-    if (measure != 1) return 0;
+    if (measure == 2) return 0;  // Kendall keeps nothing per voxel
     const size_t tiles = (num_voxels + 63) / 64;
     return size_t(cs) * 64 * 2 * sizeof(uint16_t) * (tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
 }
 
+struct SymmetricBinnedArgs {
+    int num_bins;  // <= 255: the code 0xFFFF of a skipped sample can then never equal a valid bin pair
+    float min_x, max_x, min_y, max_y;
+    int to_cc;
+};
+
+// measure 1: Spearman, 2: Kendall, 3 / 5: binned MI / its correlation coefficient (cell codes b1 << 8 | b0 in the
+// voxel's 16-bit workspace column, then counts of equal bins / cells by 16-row sweeps; the first occurrence of a bin
+// or cell contributes its term, exactly like the skipped-sample path of mi_binned_kernel)
 __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const* __restrict__ members_x,
                                                               const float* const* __restrict__ members_y,
                                                               float* __restrict__ out, size_t num_voxels, int cs,
-                                                              int measure, uint16_t* __restrict__ workspace) {
+                                                              int measure, uint16_t* __restrict__ workspace,
+                                                              SymmetricBinnedArgs ba,
+                                                              const double* __restrict__ tableT) {
     constexpr int T = kDirectRows;
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
@@ -444,6 +455,79 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
                 r += invNm1 * ((0.5f * float(rx[size_t(e) * 64]) - meanX) / sdX) *
                      ((0.5f * float(ry[size_t(e) * 64]) - meanY) / sdY);
             res = r;
+        } else if (measure == 3 || measure == 5) {
+            uint16_t* codes = rx;
+            const float range_x = ba.max_x - ba.min_x, range_y = ba.max_y - ba.min_y;
+            const double nbd = double(ba.num_bins);
+            int total = 0;
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) {
+                const float xv = load_member_cached(members_x[e], bytes, off);
+                const float yv = load_member_cached(members_y[e], bytes, off);
+                is_nan |= xv != xv || yv != yv;
+                const float x01 = (xv - ba.min_x) / range_x, y01 = (yv - ba.min_y) / range_y;
+                const bool valid = (x01 == x01) && (y01 == y01);
+                int b0 = int(double(x01) * nbd), b1 = int(double(y01) * nbd);
+                b0 = b0 < 0 ? 0 : (b0 > ba.num_bins - 1 ? ba.num_bins - 1 : b0);
+                b1 = b1 < 0 ? 0 : (b1 > ba.num_bins - 1 ? ba.num_bins - 1 : b1);
+                codes[size_t(e) * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
+                total += valid ? 1 : 0;
+            }
+            double mi = 0.0;
+            const bool table_ok = total == cs;
+            const double tot = double(total);
+            const double eps1 = 0.5 / double(cs), eps2 = 0.5 / double(cs * cs);
+#pragma unroll 1
+            for (int i0 = 0; i0 < cs && total > 0; i0 += T) {
+                uint32_t ci[T];
+                int cx[T], cy[T], cxy[T], bx[T], by[T], bxy[T];  // counts over all j / over j < i
+#pragma unroll
+                for (int r = 0; r < T; r++) {
+                    ci[r] = i0 + r < cs ? uint32_t(codes[size_t(i0 + r) * 64]) : 0xFFFFu;
+                    cx[r] = cy[r] = cxy[r] = bx[r] = by[r] = bxy[r] = 0;
+                }
+#pragma unroll 2
+                for (int j = 0; j < cs; j++) {
+                    const uint32_t cj = codes[size_t(j) * 64];
+#pragma unroll
+                    for (int r = 0; r < T; r++) {
+                        const int ex = ((cj ^ ci[r]) & 0xFFu) == 0u ? 1 : 0;
+                        const int ey = ((cj ^ ci[r]) >> 8) == 0u ? 1 : 0;
+                        const int exy = cj == ci[r] ? 1 : 0;
+                        const int before = j < i0 + r ? 1 : 0;
+                        cx[r] += ex;
+                        cy[r] += ey;
+                        cxy[r] += exy;
+                        bx[r] += ex & before;
+                        by[r] += ey & before;
+                        bxy[r] += exy & before;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < T; r++) {
+                    if (ci[r] == 0xFFFFu) continue;  // skipped sample (or a row past the end)
+                    if (table_ok) {
+                        if (bx[r] == 0) mi -= tableT[cx[r]];
+                        if (by[r] == 0) mi -= tableT[cy[r]];
+                        if (bxy[r] == 0) mi += tableT[cxy[r]];
+                    } else {
+                        if (bx[r] == 0) {
+                            const double pr = double(cx[r]) / tot;
+                            if (pr > eps1) mi -= pr * log(pr);
+                        }
+                        if (by[r] == 0) {
+                            const double pr = double(cy[r]) / tot;
+                            if (pr > eps1) mi -= pr * log(pr);
+                        }
+                        if (bxy[r] == 0) {
+                            const double pr = double(cxy[r]) / tot;
+                            if (pr > eps2) mi += pr * log(pr);
+                        }
+                    }
+                }
+            }
+            res = float(mi);
+            if (measure == 5) res = mi_to_cc_generic(res);
         } else {
             int32_t discordant = 0, n1 = 0, n2 = 0;
 #pragma unroll 1
@@ -481,14 +565,16 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
 }
 
 hipError_t launch_direct_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
-                                   size_t num_voxels, int measure, unsigned char* d_workspace, float* d_out,
+                                   size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
+                                   float max_y, const double* d_tables, unsigned char* d_workspace, float* d_out,
                                    hipStream_t s) {
-    if (measure != 1 && measure != 2) return hipErrorNotSupported;
-    if (measure == 1 && !d_workspace) return hipErrorInvalidValue;
+    if (measure != 1 && measure != 2 && measure != 3 && measure != 5) return hipErrorNotSupported;
+    if (measure != 2 && !d_workspace) return hipErrorInvalidValue;
     const size_t tiles = (num_voxels + 63) / 64;
     const unsigned blocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
+    const SymmetricBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
     hipLaunchKernelGGL(direct_symmetric_kernel, dim3(blocks), dim3(64), 0, s, d_members_x, d_members_y, d_out, num_voxels,
-                       cs, measure, reinterpret_cast<uint16_t*>(d_workspace));
+                       cs, measure, reinterpret_cast<uint16_t*>(d_workspace), ba, d_tables + (cs + 1));
     return hipGetLastError();
 }
 

@@ -668,8 +668,11 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
 // ---------------------------------------------------------------------------------------------------------------
 // Blocks of 4 waves share one copy of the tables in LDS (24 KB at 1000 members: with one wave per block LDS would cap
 // the occupancy at 1.5 waves per SIMD).
-template <int K, int TI>
+// SYM (symmetric field mode): the X side is voxel dependent too -- x_e = members_x[e][v] + noise_ref[e] (prep_px then
+// points at the noise_ref table), X counts by comparison like the Y counts instead of the binary search.
+template <int K, int TI, bool SYM = false>
 __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const* __restrict__ members,
+                                                            const float* const* __restrict__ members_x,
                                                             const double* __restrict__ prep_px,
                                                             const double* __restrict__ table_psi,
                                                             const double* __restrict__ noise_query,
@@ -681,8 +684,8 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
     double* s_nq = s_spx + cs;
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < cs; i += 256) {
-        s_px[i] = prep_px[i];
-        s_spx[i] = prep_px[cs + i];
+        s_px[i] = prep_px[i];                         // SYM: noise_ref[i]
+        s_spx[i] = SYM ? 0.0 : prep_px[cs + i];
         s_nq[i] = noise_query[i];
     }
     __syncthreads();
@@ -709,7 +712,13 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                 const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
                 const float y = load_member_cached(members[ii], bytes, off);
                 is_nan |= y != y;
-                pxi[t] = s_px[ii];
+                if constexpr (SYM) {
+                    const float x = load_member_cached(members_x[ii], bytes, off);
+                    is_nan |= x != x;
+                    pxi[t] = double(x) + s_px[ii];
+                } else {
+                    pxi[t] = s_px[ii];
+                }
                 pyi[t] = double(y) + s_nq[ii];
 #pragma unroll
                 for (int q = 0; q < K; q++) best[t][q] = inf;
@@ -718,15 +727,17 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
             //      (the member values come in batches of JB loads issued back to back: one memory latency per batch)
 #pragma unroll 1
             for (int j0 = 0; j0 < cs; j0 += JB) {
-                float yb[JB];
+                float yb[JB], xb[SYM ? JB : 1];
 #pragma unroll
-                for (int u = 0; u < JB; u++)
+                for (int u = 0; u < JB; u++) {
                     yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                    if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                }
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
                     const int j = j0 + u;
                     const int jc = j < cs ? j : cs - 1;
-                    const double pxj = s_px[jc];
+                    const double pxj = SYM ? double(xb[SYM ? u : 0]) + s_px[jc] : s_px[jc];
                     const double pyj = double(yb[u]) + s_nq[jc];
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                 for (int t = 0; t < TI; t++) ex[t] = ey[t] = 0.0;
 #pragma unroll 2
                 for (int j = 0; j < cs; j++) {
-                    const double pxj = s_px[j];
+                    const double pxj = SYM ? double(load_member_cached(members_x[j], bytes, off)) + s_px[j] : s_px[j];
                     const double pyj = double(load_member_cached(members[j], bytes, off)) + s_nq[j];
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
@@ -774,26 +785,36 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                 }
             }
             // ---- sweep C: marginal counts (:201-233)
-            double loy[TI], hiy[TI];
+            double loy[TI], hiy[TI], lox[TI], hix[TI];
             int cx[TI], cy[TI];
 #pragma unroll
             for (int t = 0; t < TI; t++) {
-                cx[t] = count_less(s_spx, cs, top, pxi[t] + rx[t]) - count_less(s_spx, cs, top, pxi[t] - rx[t]);
+                lox[t] = pxi[t] - rx[t];
+                hix[t] = pxi[t] + rx[t];
+                cx[t] = SYM ? 0 : count_less(s_spx, cs, top, hix[t]) - count_less(s_spx, cs, top, lox[t]);
                 loy[t] = pyi[t] - ry[t];
                 hiy[t] = pyi[t] + ry[t];
                 cy[t] = 0;
             }
 #pragma unroll 1
             for (int j0 = 0; j0 < cs; j0 += JB) {
-                float yb[JB];
-#pragma unroll
-                for (int u = 0; u < JB; u++)
-                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                float yb[JB], xb[SYM ? JB : 1];
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
-                    const double pyj = double(yb[u]) + s_nq[j0 + u < cs ? j0 + u : cs - 1];
+                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                    if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                }
+#pragma unroll
+                for (int u = 0; u < JB; u++) {
+                    const int jc = j0 + u < cs ? j0 + u : cs - 1;
+                    const double pyj = double(yb[u]) + s_nq[jc];
 #pragma unroll
                     for (int t = 0; t < TI; t++) cy[t] += (j0 + u < cs && pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
+                    if constexpr (SYM) {
+                        const double pxj = double(xb[u]) + s_px[jc];
+#pragma unroll
+                        for (int t = 0; t < TI; t++) cx[t] += (j0 + u < cs && pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
+                    }
                 }
             }
 #pragma unroll
@@ -953,7 +974,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
 #define CRF_LAUNCH_DIRECT(K, TI)                                                                                    \
-    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, prep, psi,        \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, prep, psi, \
                        noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
     if (kk <= 4) {
         CRF_LAUNCH_DIRECT(4, 8);
@@ -971,6 +992,38 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
 #undef CRF_LAUNCH_DIRECT
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "kraskov_direct_kernel";
+    return hipGetLastError();
+}
+
+// symmetric field mode: X = d_members_x (reference field), Y = d_members_y (query field); KSG-1
+hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                       size_t num_voxels, int k, bool to_cc, const double* d_tables, float* d_out,
+                                       hipStream_t s) {
+    if (cs == 1) return launch_fill(d_out, num_voxels, 1.0f, s);
+    const int kk = k < cs - 1 ? k : cs - 1;
+    const size_t lds = size_t(3 * cs) * sizeof(double);
+    if (kk > 64 || lds > 60 * 1024) return hipErrorNotSupported;
+    const double* psi = d_tables;
+    const double* noise_ref = d_tables + 2 * (cs + 1);
+    const double* noise_query = noise_ref + cs;
+    const size_t tiles = (num_voxels + 63) / 64;
+    const size_t groups = (tiles + 3) / 4;
+    const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
+#define CRF_LAUNCH_SYM(K, TI)                                                                                        \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, true>), dim3(blocks), dim3(256), lds, s, d_members_y, d_members_x, \
+                       noise_ref, psi, noise_query, d_out, num_voxels, cs, k, 1, int(to_cc))
+    if (kk <= 4) {
+        CRF_LAUNCH_SYM(4, 8);
+    } else if (kk <= 8) {
+        CRF_LAUNCH_SYM(8, 4);
+    } else if (kk <= 16) {
+        CRF_LAUNCH_SYM(16, 2);
+    } else if (kk <= 32) {
+        CRF_LAUNCH_SYM(32, 1);
+    } else {
+        CRF_LAUNCH_SYM(64, 1);
+    }
+#undef CRF_LAUNCH_SYM
     return hipGetLastError();
 }
 
