@@ -388,12 +388,14 @@ struct SymmetricBinnedArgs {
 // measure 1: Spearman, 2: Kendall, 3 / 5: binned MI / its correlation coefficient (cell codes b1 << 8 | b0 in the
 // voxel's 16-bit workspace column, then counts of equal bins / cells by 16-row sweeps; the first occurrence of a bin
 // or cell contributes its term, exactly like the skipped-sample path of mi_binned_kernel)
+// (one instantiation per measure: sharing one kernel cost Kendall 60 % through register allocation)
+template <int MEASURE>
 __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const* __restrict__ members_x,
                                                               const float* const* __restrict__ members_y,
                                                               float* __restrict__ out, size_t num_voxels, int cs,
-                                                              int measure, uint16_t* __restrict__ workspace,
-                                                              SymmetricBinnedArgs ba,
+                                                              uint16_t* __restrict__ workspace, SymmetricBinnedArgs ba,
                                                               const double* __restrict__ tableT) {
+    constexpr int measure = MEASURE;
     constexpr int T = kDirectRows;
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
         const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
         float res;
         bool is_nan = false;
-        if (measure == 1) {
+        if constexpr (measure == 1) {
 #pragma unroll 1
             for (int side = 0; side < 2; side++) {
                 const float* const* __restrict__ m = side == 0 ? members_x : members_y;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
                 r += invNm1 * ((0.5f * float(rx[size_t(e) * 64]) - meanX) / sdX) *
                      ((0.5f * float(ry[size_t(e) * 64]) - meanY) / sdY);
             res = r;
-        } else if (measure == 3 || measure == 5) {
+        } else if constexpr (measure == 3 || measure == 5) {
             uint16_t* codes = rx;
             const float range_x = ba.max_x - ba.min_x, range_y = ba.max_y - ba.min_y;
             const double nbd = double(ba.num_bins);
@@ -573,8 +575,18 @@ hipError_t launch_direct_symmetric(const float* const* d_members_x, const float*
     const size_t tiles = (num_voxels + 63) / 64;
     const unsigned blocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
     const SymmetricBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
-    hipLaunchKernelGGL(direct_symmetric_kernel, dim3(blocks), dim3(64), 0, s, d_members_x, d_members_y, d_out, num_voxels,
-                       cs, measure, reinterpret_cast<uint16_t*>(d_workspace), ba, d_tables + (cs + 1));
+    uint16_t* ws = reinterpret_cast<uint16_t*>(d_workspace);
+    const double* tableT = d_tables + (cs + 1);
+#define CRF_LAUNCH_SYMMETRIC(M)                                                                                       \
+    hipLaunchKernelGGL((direct_symmetric_kernel<M>), dim3(blocks), dim3(64), 0, s, d_members_x, d_members_y, d_out,   \
+                       num_voxels, cs, ws, ba, tableT)
+    switch (measure) {
+        case 1: CRF_LAUNCH_SYMMETRIC(1); break;
+        case 2: CRF_LAUNCH_SYMMETRIC(2); break;
+        case 3: CRF_LAUNCH_SYMMETRIC(3); break;
+        default: CRF_LAUNCH_SYMMETRIC(5); break;
+    }
+#undef CRF_LAUNCH_SYMMETRIC
     return hipGetLastError();
 }
 
