@@ -270,11 +270,12 @@ size_t direct_rank_workspace_bytes(int cs, size_t num_voxels, int measure) {
     return size_t(cs) * 64 * sizeof(uint16_t) * (tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
 }
 
-// measure 1: Spearman (prep = float a_e), 2: Kendall (prep = int perm / gend / n1 with stride cs)
+// MEASURE 1: Spearman (prep = float a_e), 2: Kendall (prep = int perm / gend / n1 with stride cs)
+template <int MEASURE>
 __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __restrict__ members,
                                                          const void* __restrict__ prep, float* __restrict__ out,
-                                                         size_t num_voxels, int cs, int measure,
-                                                         uint16_t* __restrict__ workspace) {
+                                                         size_t num_voxels, int cs, uint16_t* __restrict__ workspace) {
+    constexpr int measure = MEASURE;
     constexpr int T = kDirectRows;
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
         const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
         float res;
         bool is_nan = false;
-        if (measure == 1) {
+        if constexpr (measure == 1) {
 #pragma unroll 1
             for (int e0 = 0; e0 < cs; e0 += T) {
                 float ve[T];
@@ -938,8 +939,14 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
         const unsigned dblocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
         if (a.measure == 1 && !d_workspace) return hipErrorInvalidValue;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
-        hipLaunchKernelGGL(direct_rank_kernel, dim3(dblocks), dim3(64), 0, s, d_members, static_cast<const void*>(d_prep),
-                           d_out, num_voxels, cs, a.measure, reinterpret_cast<uint16_t*>(d_workspace));
+        if (a.measure == 1)
+            hipLaunchKernelGGL(direct_rank_kernel<1>, dim3(dblocks), dim3(64), 0, s, d_members,
+                               static_cast<const void*>(d_prep), d_out, num_voxels, cs,
+                               reinterpret_cast<uint16_t*>(d_workspace));
+        else
+            hipLaunchKernelGGL(direct_rank_kernel<2>, dim3(dblocks), dim3(64), 0, s, d_members,
+                               static_cast<const void*>(d_prep), d_out, num_voxels, cs,
+                               reinterpret_cast<uint16_t*>(d_workspace));
         if (ev_end) (void)hipEventRecord(ev_end, s);
         if (info) info->kernel_name = "direct_rank_kernel";
         return hipGetLastError();
