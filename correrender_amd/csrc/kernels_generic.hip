@@ -341,15 +341,27 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
                     yi[r] = load_member_cached(members[prep_i[i]], bytes, off);
                     is_nan |= yi[r] != yi[r];
                     gi[r] = i0 + r < cs ? gend[i] : cs;
+                    if (i0 + r >= cs) yi[r] = __uint_as_float(0x7FC00000u);  // a row past the end matches nothing
                 }
-#pragma unroll 2
-                for (int j = i0 + 1; j < cs; j++) {
+                // the block's own columns: row r only counts j > i0 + r
+#pragma unroll 1
+                for (int j = i0 + 1; j < i0 + T && j < cs; j++) {
                     const float yj = load_member_cached(members[prep_i[j]], bytes, off);
 #pragma unroll
                     for (int r = 0; r < T; r++) {
-                        const bool after = j > i0 + r && i0 + r < cs;
+                        const bool after = j > i0 + r;
                         n2 += (after && yj == yi[r]) ? 1 : 0;
                         discordant += (after && j > gi[r] && yi[r] > yj) ? 1 : 0;
+                    }
+                }
+                // every later column counts for all rows of the block
+#pragma unroll 4
+                for (int j = i0 + T; j < cs; j++) {
+                    const float yj = load_member_cached(members[prep_i[j]], bytes, off);
+#pragma unroll
+                    for (int r = 0; r < T; r++) {
+                        n2 += (yj == yi[r]) ? 1 : 0;
+                        discordant += (j > gi[r] && yi[r] > yj) ? 1 : 0;
                     }
                 }
             }
