@@ -115,13 +115,17 @@ def main():
 
     pts = reference_points(xs, ys, zs, args.warmup + args.steps)
 
+    # one GPU: the same batched pipeline without any collective (reference vectors gathered and the reference-side
+    # tables prepared a batch ahead on the side stream) when CRF_BENCH_LOCAL_BATCH=1; default: plain per-step calls
+    # (measured at 256^3 x 64: 0.700 vs 0.696 ms/step -- at one GPU the preparation is 0.7 % of a step, no gain)
+    local_batches = not multi and os.environ.get("CRF_BENCH_LOCAL_BATCH", "0") == "1"
     LOOKAHEAD = int(os.environ.get("CRF_BENCH_LOOKAHEAD", "16"))  # reference vectors exchanged per collective (N > 1), <= 32
 
     def run(lo, hi):
         """Steps lo..hi-1.  N > 1: the reference vectors of the next LOOKAHEAD requested points are exchanged in ONE
         collective (owners gather on their device -> RCCL all-reduce of LOOKAHEAD*cs floats) on the communication stream,
         one batch ahead of the kernels that consume them, so the exchange overlaps the evaluation of earlier steps."""
-        if not multi:
+        if not multi and not local_batches:
             for i in range(lo, hi):
                 sharded.compute(measure, out, pts[i], **kwargs)
             return
