@@ -259,8 +259,10 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (xs <= 0 || ys <= 0 || zs <= 0 || cs <= 0)
         return fail(c, CRF_ERR_ARGUMENT, fmt("invalid grid %dx%dx%d with %d members", xs, ys, zs, cs));
     const size_t n = size_t(xs) * size_t(ys) * size_t(zs);
-    if (n * sizeof(float) >= (size_t(1) << 32))
-        return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) larger than 4 GiB is not supported; shard it");
+    // 32-bit byte offsets inside a member, and the kernels' out-of-range sentinel offset (crf_device.h
+    // kOutOfRangeOffset = 0xFFFFFFF0) must lie beyond the end of every member
+    if (n * sizeof(float) >= size_t(0xFFFFFFF0u))
+        return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) of 4 GiB or more is not supported; shard it");
     if (int r = bind_device(c)) return r;
     release_members(c);
     release_secondary(c);
