@@ -2,7 +2,7 @@
 // correlation-field path touches.  Same names, argument meaning and behaviour as
 //   class Calculator              /root/reference/src/Calculators/Calculator.hpp:86-138
 //   enum class FilterDevice       Calculator.hpp:79-81
-//   enum class CalculatorType     Calculator.hpp:57-63  (only CORRELATION is used here)
+//   enum class CalculatorType     Calculator.hpp:57-63  (the ensemble calculators implemented here)
 //   class SettingsMap             /root/reference/src/Utils/InternalState.hpp:41-113
 // so that tests against this mirror read like tests against the reference classes, and so that the reference-side
 // subclass shown in INTEGRATION.md is a line-for-line transplant.  No rendering, GUI or Vulkan types.
@@ -19,7 +19,9 @@
 namespace crfhost {
 
 enum class FieldType : uint32_t { SCALAR = 0 };
-enum class CalculatorType : uint32_t { CORRELATION = 10, INVALID = 16 };
+enum class CalculatorType : uint32_t {  // values of Calculator.hpp:57-63
+    ENSEMBLE_MEAN = 6, ENSEMBLE_SPREAD = 7, SET_PREDICATE = 8, CORRELATION = 10, DKL_CALCULATOR = 15, INVALID = 16
+};
 enum class FilterDevice { CPU, VULKAN, CUDA };
 
 // All values are strings; booleans accept "1"/"true" (InternalState.hpp:56-62).

@@ -62,7 +62,7 @@ public:
     void addCalculator(const CalculatorPtr& calculator);
     /// Evicts the cached outputs of dirty calculators (the role of VolumeData::renderGuiCalculators, :1852-1936).
     void updateCalculators();
-    size_t getNewCalculatorUseCount(CalculatorType) { return ++calculatorUseCount; }
+    size_t getNewCalculatorUseCount(CalculatorType t) { return ++calculatorTypeUseCounts[t]; }  // VolumeData.cpp:2283-2285
     /// Monotonic id of the input data (changes whenever setFieldData is called): lets a calculator keep a device copy.
     uint64_t getDataGeneration() const { return dataGeneration; }
 
@@ -75,7 +75,7 @@ private:
     std::map<Access, std::pair<float, float>> fieldMinMaxCache;
     std::map<std::string, CalculatorPtr> calculatorsHost;
     std::vector<CalculatorPtr> calculators;
-    size_t calculatorUseCount = 0;
+    std::map<CalculatorType, size_t> calculatorTypeUseCounts;
     uint64_t dataGeneration = 0;
 };
 

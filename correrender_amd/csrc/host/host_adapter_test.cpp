@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "CorrelationCalculator.hpp"
+#include "EnsembleCalculators.hpp"
 #include "NetCdfLoader.hpp"
 
 using namespace crfhost;
@@ -112,6 +113,33 @@ static int testSettings() {
     volT->addCalculator(calcT);
     CHECK(!calcT->getIsEnsembleMode() && calcT->getCorrelationMemberCount() == 10);
     CHECK(calcT->getKraskovNumNeighbors() == 1);
+    // ---- the sibling ensemble calculators: names, per-type numbering, settings keys, defaults
+    auto volS = makeVolume(8, 8, 4, 1, 50, 1, nullptr);
+    auto mean = std::make_shared<EnsembleMeanCalculator>(0);
+    auto spread = std::make_shared<EnsembleSpreadCalculator>(0);
+    auto pred = std::make_shared<SetPredicateCalculator>(0);
+    auto dkl = std::make_shared<DKLCalculator>(0);
+    auto dkl2 = std::make_shared<DKLCalculator>(0);
+    for (CalculatorPtr c : {CalculatorPtr(mean), CalculatorPtr(spread), CalculatorPtr(pred), CalculatorPtr(dkl), CalculatorPtr(dkl2)})
+        volS->addCalculator(c);
+    CHECK(mean->getOutputFieldName() == "Ensemble Mean" && spread->getOutputFieldName() == "Ensemble Variance");
+    CHECK(pred->getOutputFieldName() == "Set Predicate" && dkl->getOutputFieldName() == "KL-Divergence");
+    CHECK(dkl2->getOutputFieldName() == "KL-Divergence (2)");  // numbered per calculator type (VolumeData.cpp:2283-2285)
+    CHECK(pred->getCountLower() == 25 && pred->getCountUpper() == 25);  // cs / 2 (SetPredicateCalculator.cpp:143-144)
+    CHECK(dkl->getNumNeighbors() == 2);                                  // max(ceil(3 * 50 / 100), 1)
+    pred->setSettings(SettingsMap{{"comparison_operator_type", "<="}, {"comparison_value", "0.5"}, {"count_lower", "10"},
+                                   {"count_upper", "40"}});
+    SettingsMap ps;
+    pred->getSettings(ps);
+    CHECK(ps.getMap().at("comparison_operator_type") == "<=" && ps.getMap().at("count_lower") == "10" &&
+          ps.getMap().at("count_upper") == "40" && ps.getMap().at("comparison_value") == "0.5" &&
+          ps.getMap().at("correlation_mode") == "Ensemble" && ps.getMap().at("scalar_field_idx") == "0");
+    dkl->setSettings(SettingsMap{{"estimator_type", "Binning"}, {"mi_bins", "32"}, {"knn_neighbors", "5"}});
+    SettingsMap ds;
+    dkl->getSettings(ds);
+    CHECK(ds.getMap().at("estimator_type") == "Binning" && ds.getMap().at("mi_bins") == "32" &&
+          ds.getMap().at("knn_neighbors") == "5");
+    CHECK(pred->getHasFixedRange() && pred->getFixedRange() == std::make_pair(0.0f, 1.0f));
     std::puts("SETTINGS-OK");
     return 0;
 }
@@ -170,6 +198,24 @@ static int testCompute(const char* inPath, const std::string& outDir) {
         eval("kendall_symmetric", tFixed, 0);
         calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_binned"}});
         eval("binned_symmetric", tFixed, 0);
+    }
+    {  // the sibling ensemble calculators on the first field
+        auto mean = std::make_shared<EnsembleMeanCalculator>(0);
+        auto spread = std::make_shared<EnsembleSpreadCalculator>(0);
+        auto pred = std::make_shared<SetPredicateCalculator>(0);
+        auto dklK = std::make_shared<DKLCalculator>(0);
+        auto dklB = std::make_shared<DKLCalculator>(0);
+        for (CalculatorPtr c : {CalculatorPtr(mean), CalculatorPtr(spread), CalculatorPtr(pred), CalculatorPtr(dklK), CalculatorPtr(dklB)})
+            vol->addCalculator(c);
+        pred->setSettings(SettingsMap{{"comparison_operator_type", ">"}, {"comparison_value", "0.25"}});
+        dklB->setSettings(SettingsMap{{"estimator_type", "Binning"}, {"mi_bins", "16"}});
+        vol->updateCalculators();
+        const char* tags[5] = {"ensemble_mean", "ensemble_spread", "set_predicate", "dkl_knn", "dkl_binned"};
+        CalculatorPtr calcs[5] = {mean, spread, pred, dklK, dklB};
+        for (int i = 0; i < 5; i++) {
+            HostCacheEntry entry = vol->getFieldEntryCpu(FieldType::SCALAR, calcs[i]->getOutputFieldName(), tFixed, 0);
+            dump(outDir + "/" + tags[i] + ".bin", entry->data<float>(), n);
+        }
     }
     std::printf("COMPUTE-OK kernel_ms=%.4f\n", calc->getLastKernelTimeMs());
     return 0;

@@ -64,6 +64,12 @@ def test_calculate_cpu_ensemble_mode(tmp_path, oracle):
                                                       minmax_ref=oracle.minmax(ens2), minmax_query=mm), "separate binned")
     ref_lag = data[1, 0][:, 3, 2, 1].copy()                                      # time-lag: field 2 at time step 0
     assert_bit_exact(out("pearson_separate_lag0"), oracle.field(oracle_lib.PEARSON, ens, ref_lag), "time lag")
+    # sibling ensemble calculators (EnsembleMean / Spread / SetPredicate / DKL mirrors) on field 1 at the same time step
+    assert_bit_exact(out("ensemble_mean"), oracle.ensemble_stat(0, ens), "adapter ensemble mean")
+    assert_bit_exact(out("ensemble_spread"), oracle.ensemble_stat(1, ens), "adapter ensemble spread")
+    assert_bit_exact(out("set_predicate"), oracle.set_predicate(0, 0.25, cs // 2, cs // 2, ens), "adapter set predicate")
+    assert_close(out("dkl_knn"), oracle.dkl(1, ens, k=default_kraskov_k(cs)), "adapter DKL k-NN")
+    assert_close(out("dkl_binned"), oracle.dkl(0, ens, num_bins=16), "adapter DKL binned")
     # SEPARATE_SYMMETRIC: field 1 (reference side) vs field 2 (query side) at every voxel
     assert_bit_exact(out("kendall_symmetric"), oracle.symmetric_field(oracle_lib.KENDALL, ens, ens2), "symmetric kendall")
     assert_close(out("binned_symmetric"), oracle.symmetric_field(oracle_lib.MI_BINNED, ens, ens2, num_bins=80,
