@@ -80,6 +80,41 @@ def main():
         mi_binned__restatement=oracle.pair_requests(3, ens, ii, jj, num_bins=80),
         mi_kraskov__restatement=oracle.pair_requests(4, ens, ii, jj, k=3))
     print("pair_requests: 300 requests, cs=32")
+    # two-field modes and sibling reductions.  Symmetric Pearson/Spearman/Kendall expectations
+    # come from the reference's primitives applied voxel by voxel to (field 1, field 2); everything else from the
+    # restatement (regression pins).
+    rng = np.random.default_rng(4711)
+    fa = rng.standard_normal((24, 4, 6, 8)).astype(np.float32)
+    fb = (0.6 * fa + 0.8 * rng.standard_normal((24, 4, 6, 8))).astype(np.float32)
+    fb[:, 0, 0, 0] = fa[:, 0, 0, 0]
+    fa[:, 1, 1, 1] = np.round(fa[:, 1, 1, 1])          # ties on the reference side
+    fb[3, 2, 2, 2] = np.nan
+    n = fa[0].size
+    flat_a, flat_b = fa.reshape(24, n), fb.reshape(24, n)
+    sym = {m: np.empty(n, np.float32) for m in ("pearson", "spearman", "kendall")}
+    for v in range(n):
+        x, y = flat_a[:, v].copy(), flat_b[:, v].copy()
+        if np.isnan(x).any() or np.isnan(y).any():
+            for m in sym:
+                sym[m][v] = np.nan
+            continue
+        sym["pearson"][v] = ref.pearson(x, y)
+        sym["spearman"][v] = ref.pearson(ref.ranks(x), ref.ranks(y))
+        sym["kendall"][v] = ref.kendall(x, y)
+    mm_a, mm_b = oracle.minmax(fa), (float(np.nanmin(fb)), float(np.nanmax(fb)))
+    np.savez_compressed(
+        OUT / "two_fields_and_siblings.npz", field_a=fa, field_b=fb, minmax_a=np.array(mm_a, np.float32),
+        minmax_b=np.array(mm_b, np.float32),
+        symmetric_pearson__reference=sym["pearson"], symmetric_spearman__reference=sym["spearman"],
+        symmetric_kendall__reference=sym["kendall"],
+        symmetric_mi_binned__restatement=oracle.symmetric_field(3, fa, fb, num_bins=20, minmax_ref=mm_a, minmax_query=mm_b),
+        symmetric_mi_kraskov__restatement=oracle.symmetric_field(4, fa, fb, k=3),
+        ensemble_mean__restatement=oracle.ensemble_stat(0, fb), ensemble_spread__restatement=oracle.ensemble_stat(1, fb),
+        set_predicate_gt__restatement=oracle.set_predicate(0, 0.25, 8, 16, fa),
+        set_predicate_le__restatement=oracle.set_predicate(3, -0.5, 12, 12, fa),
+        dkl_binned__restatement=oracle.dkl(0, fa, num_bins=16), dkl_knn__restatement=oracle.dkl(1, fa, k=2),
+        tiled_member0__restatement=oracle.tile_field(fa[0]))
+    print("two_fields_and_siblings: 192 voxels, cs=24")
     # known-answer vectors (computed by the reference object code)
     x = np.array([1, 1, 2, 2, 3, 3, 4, 4], np.float32)
     y = np.array([1, 2, 2, 3, 3, 3, 5, 4], np.float32)

@@ -12,7 +12,7 @@ import oracle_lib
 from parity import assert_bit_exact
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if p.stem not in ("known_answers", "pair_requests"))
+CASES = sorted(p.stem for p in GOLDEN.glob("*.npz") if p.stem not in ("known_answers", "pair_requests", "two_fields_and_siblings"))
 
 
 def test_golden_cases_present():
@@ -67,3 +67,23 @@ def test_edge_semantics_in_golden():
     for key in one.files:
         if "__" in key:
             assert (one[key] == 1.0).all(), key            # cs == 1 -> 1.0 for every measure
+
+
+def test_two_field_modes_and_siblings(oracle):
+    """Symmetric Pearson / Spearman / Kendall expectations are the reference's primitives applied voxel by voxel; the
+    rest pins the restatement."""
+    d = np.load(GOLDEN / "two_fields_and_siblings.npz")
+    fa, fb = d["field_a"], d["field_b"]
+    mm_a, mm_b = tuple(map(float, d["minmax_a"])), tuple(map(float, d["minmax_b"]))
+    for name, m in (("pearson", 0), ("spearman", 1), ("kendall", 2)):
+        assert_bit_exact(oracle.symmetric_field(m, fa, fb), d[f"symmetric_{name}__reference"], f"symmetric {name}")
+    assert_bit_exact(oracle.symmetric_field(3, fa, fb, num_bins=20, minmax_ref=mm_a, minmax_query=mm_b),
+                     d["symmetric_mi_binned__restatement"], "symmetric binned")
+    assert_bit_exact(oracle.symmetric_field(4, fa, fb, k=3), d["symmetric_mi_kraskov__restatement"], "symmetric kraskov")
+    assert_bit_exact(oracle.ensemble_stat(0, fb), d["ensemble_mean__restatement"], "mean")
+    assert_bit_exact(oracle.ensemble_stat(1, fb), d["ensemble_spread__restatement"], "spread")
+    assert_bit_exact(oracle.set_predicate(0, 0.25, 8, 16, fa), d["set_predicate_gt__restatement"], "set predicate >")
+    assert_bit_exact(oracle.set_predicate(3, -0.5, 12, 12, fa), d["set_predicate_le__restatement"], "set predicate <=")
+    assert_bit_exact(oracle.dkl(0, fa, num_bins=16), d["dkl_binned__restatement"], "dkl binned")
+    assert_bit_exact(oracle.dkl(1, fa, k=2), d["dkl_knn__restatement"], "dkl knn")
+    np.testing.assert_array_equal(oracle.tile_field(fa[0]), d["tiled_member0__restatement"])
