@@ -53,13 +53,16 @@ def test_full_size_sampled_parity_and_properties(engine, oracle, volume):
     results = {}
     for m, om, exact in ((Measure.PEARSON, oracle_lib.PEARSON, True), (Measure.SPEARMAN, oracle_lib.SPEARMAN, True),
                          (Measure.KENDALL, oracle_lib.KENDALL, True),
-                         (Measure.MUTUAL_INFORMATION_BINNED, oracle_lib.MI_BINNED, False)):
+                         (Measure.MUTUAL_INFORMATION_BINNED, oracle_lib.MI_BINNED, False),
+                         (Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV, False)):   # BASELINE configs[2]: k = 3
         kw = {}
         okw = {}
-        if not exact:
+        if m == Measure.MUTUAL_INFORMATION_BINNED:
             mm = engine.member_minmax()
             kw = dict(num_bins=80, minmax_ref=mm, minmax_query=mm)
             okw = dict(num_bins=80, minmax_ref=mm)
+        if m == Measure.MUTUAL_INFORMATION_KRASKOV:
+            kw = okw = dict(k=3)
         engine.compute_device(m, out, ref_xyz, **kw)
         torch.cuda.synchronize()
         got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
@@ -81,3 +84,43 @@ def test_full_size_sampled_parity_and_properties(engine, oracle, volume):
     p = results[Measure.PEARSON].view(ZS, YS, XS)
     assert float(p[ZS // 2, YS // 8 + 2, XS // 8 + 3]) == pytest.approx(1.0, abs=1e-6)
     assert abs(float(p[ZS // 2, YS // 2, XS // 2])) < 0.6                        # an uncorrelated voxel
+
+
+def test_config4_spearman_512cubed_128_members(engine, oracle):
+    """BASELINE.json configs[3]: 512^3 x 128 members, Spearman, one GPU (68.7 GB generated on the device): sampled voxels
+    bit-exact vs the oracle, and a z-slab evaluated on its own equals the corresponding part of the whole field."""
+    xs = ys = zs = 512
+    cs = 128
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs 80 GB of free HBM")
+    members = torch.empty((cs, zs, ys, xs), dtype=torch.float32, device="cuda")
+    try:
+        for c in range(cs):
+            engine.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, SEED)
+        torch.cuda.synchronize()
+        engine.set_grid(xs, ys, zs, cs)
+        engine.bind_members(members)
+        ref_xyz = (xs // 8, ys // 8, zs // 2)
+        ref_values = engine.gather_reference(*ref_xyz)
+        rng = np.random.default_rng(11)
+        idx = np.unique(np.concatenate([rng.choice(xs * ys * zs, size=20000, replace=False),
+                                        [(ref_xyz[2] * ys + ref_xyz[1]) * xs + ref_xyz[0]]])).astype(np.int64)
+        didx = torch.from_numpy(idx).cuda()
+        cols = np.ascontiguousarray(members.view(cs, -1)[:, didx].cpu().numpy()).reshape(cs, 1, 1, -1)
+        out = torch.empty(xs * ys * zs, dtype=torch.float32, device="cuda")
+        engine.compute_device(Measure.SPEARMAN, out, ref_xyz)
+        torch.cuda.synchronize()
+        assert_bit_exact(out[didx].cpu().numpy(), oracle.field(oracle_lib.SPEARMAN, cols, ref_values),
+                         "Spearman 512^3x128 sampled")
+        assert float(out[(ref_xyz[2] * ys + ref_xyz[1]) * xs + ref_xyz[0]]) == pytest.approx(1.0, abs=1e-6)
+        z0, zl = 200, 16
+        engine.set_grid(xs, ys, zl, cs)
+        engine.bind_members(members[:, z0:z0 + zl])
+        slab = torch.empty(xs * ys * zl, dtype=torch.float32, device="cuda")
+        engine.compute_device(Measure.SPEARMAN, slab, device_reference=torch.from_numpy(ref_values).cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(slab.view(torch.int32), out.view(zs, ys * xs)[z0:z0 + zl].reshape(-1).view(torch.int32))
+    finally:
+        del members
+        torch.cuda.empty_cache()
