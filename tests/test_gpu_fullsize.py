@@ -124,3 +124,44 @@ def test_config4_spearman_512cubed_128_members(engine, oracle):
     finally:
         del members
         torch.cuda.empty_cache()
+
+
+def test_config5_pearson_slab_of_1024cubed_256_members(engine, oracle):
+    """BASELINE.json configs[4]: 1024^3 x 256 members sharded over 8 GPUs -- this is ONE rank's share on one GPU: the
+    z-slab [448, 576) of the 1024^3 grid (137 GB generated on the device with the global coordinates), Pearson against a
+    reference vector handed in as the exchange would deliver it; sampled voxels bit-exact vs the oracle."""
+    xs = ys = 1024
+    zs_global, z0, zl = 1024, 448, 128
+    cs = 256
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2**30:
+        pytest.skip("needs 150 GB of free HBM")
+    members = torch.empty((cs, zl, ys, xs), dtype=torch.float32, device="cuda")
+    try:
+        for c in range(cs):
+            engine.synth_box_member(members[c], xs, ys, zl, z0, zs_global, c, cs, SEED)
+        torch.cuda.synchronize()
+        engine.set_grid(xs, ys, zl, cs)
+        engine.bind_members(members)
+        ref_local = (xs // 8, ys // 8, zs_global // 2 - z0)                      # the global centre slice lies in this slab
+        ref_values = engine.gather_reference(*ref_local)
+        rng = np.random.default_rng(12)
+        n = xs * ys * zl
+        idx = np.unique(np.concatenate([rng.choice(n, size=20000, replace=False),
+                                        [(ref_local[2] * ys + ref_local[1]) * xs + ref_local[0]]])).astype(np.int64)
+        didx = torch.from_numpy(idx).cuda()
+        cols = np.ascontiguousarray(members.view(cs, -1)[:, didx].cpu().numpy()).reshape(cs, 1, 1, -1)
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        engine.set_profiling(True)
+        engine.take_kernel_time()
+        engine.compute_device(Measure.PEARSON, out, device_reference=torch.from_numpy(ref_values).cuda())
+        torch.cuda.synchronize()
+        ms, launches = engine.take_kernel_time()
+        engine.set_profiling(False)
+        assert_bit_exact(out[didx].cpu().numpy(), oracle.field(oracle_lib.PEARSON, cols, ref_values),
+                         "Pearson 1024x1024x128 slab x 256 sampled")
+        print(f"\nconfig 5 slab: kernel {ms / max(launches, 1):.2f} ms, "
+              f"{n * (4 * cs + 4) / (ms / max(launches, 1)) / 1e6:.0f} GB/s")
+    finally:
+        del members
+        torch.cuda.empty_cache()
