@@ -101,7 +101,9 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VPT]) {
 }
 
 // launch_pearson pads cs to the next multiple of this: only the last granule of a guarded instantiation can be padding
-constexpr int pad_granule(int cs_pad) { return cs_pad <= 16 ? 8 : cs_pad <= 128 ? 16 : cs_pad <= 256 ? 32 : 64; }
+constexpr int pad_granule(int cs_pad) {
+    return cs_pad <= 16 ? 8 : cs_pad <= 128 ? 16 : cs_pad <= 224 ? 32 : cs_pad <= 240 ? 16 : cs_pad <= 256 ? 8 : 64;
+}
 
 template <int CS_PAD, int VPT, bool EXACT, int MIN_WAVES, int BLOCK = 256, bool NT = true>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const float* const* __restrict__ members,
@@ -123,6 +125,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
     for (int e = 0; e < CS_PAD; e++) {
         if (e < kFirstGuarded) {
             load_vec<VPT, NT>(members[e], bytes, byte_offset, y[e]);
+        } else if (CS_PAD >= 224) {
+            // the widest kernels have no register to spare for per-slot offsets: a uniform branch around each of the
+            // few guarded loads instead (they are the last loads issued)
+#pragma unroll
+            for (int v = 0; v < VPT; v++) y[e][v] = 0.0f;
+            if (e < cs) load_vec<VPT, NT>(members[e], bytes, byte_offset, y[e]);
         } else {
             load_vec<VPT, NT>(members[e < cs ? e : cs - 1], bytes, e < cs ? byte_offset : kOutOfRangeOffset, y[e]);
         }
@@ -348,16 +356,40 @@ __global__ void fill_kernel(float* __restrict__ out, size_t n, float value) {
 
 namespace {
 
+int env_int(const char* name, int fallback);
+
 template <int CS_PAD, int VPT>
 void launch_reg(const float* const* d_members, const float* d_prep, float* d_out, size_t blocks, size_t num_voxels,
                 int cs, hipStream_t s) {
     // occupancy request: data registers are CS_PAD*VPT per lane; ask for the waves/SIMD that budget allows.
     constexpr int kData = CS_PAD * VPT;
     constexpr int kMinWaves = kData <= 64 ? 4 : (kData <= 128 ? 2 : 1);
+    // 161..256 values per lane: capped at 256 registers (two waves per SIMD; 12-120 B of scratch) the kernel is 1.2x
+    // faster than with 256 VGPRs + AGPRs at one wave per SIMD, which cannot overlap its load and compute phases --
+    // measured at 512x512x128: 256 members 8.15 -> 6.72 ms (64 % of the HBM peak), 224 members 5.60 -> 4.63 ms (81 %),
+    // 200 (guarded 224) 5.61 -> 4.53 ms.  The guarded 248 / 256 instantiations spill ~1 KB under the cap (28 ms): they stay
+    // at one wave.  CRF_PEARSON_WAVES=1 restores the one-wave kernels (tuning).
+    constexpr bool kTwoWavesExact = kData > 160 && kData <= 256;
+    constexpr bool kTwoWavesGuarded = kData > 160 && kData <= 240;
+    const bool two = env_int("CRF_PEARSON_WAVES", 2) == 2;
     if (cs == CS_PAD) {
+        if constexpr (kTwoWavesExact) {
+            if (two) {
+                hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, true, 2>), dim3(unsigned(blocks)), dim3(256), 0, s,
+                                   d_members, d_prep, d_out, uint32_t(num_voxels), cs);
+                return;
+            }
+        }
         hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, true, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0, s,
                            d_members, d_prep, d_out, uint32_t(num_voxels), cs);
     } else {
+        if constexpr (kTwoWavesGuarded) {
+            if (two) {
+                hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, false, 2>), dim3(unsigned(blocks)), dim3(256), 0, s,
+                                   d_members, d_prep, d_out, uint32_t(num_voxels), cs);
+                return;
+            }
+        }
         hipLaunchKernelGGL((pearson_reg_kernel<CS_PAD, VPT, false, kMinWaves>), dim3(unsigned(blocks)), dim3(256), 0,
                            s, d_members, d_prep, d_out, uint32_t(num_voxels), cs);
     }
@@ -439,8 +471,8 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     if (cs <= kMaxRegisterMembers) {
-        const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : cs <= 256 ? (cs + 31) / 32 * 32
-                                                                                    : (cs + 63) / 64 * 64;
+        const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : cs <= 224 ? (cs + 31) / 32 * 32
+                         : cs <= 240 ? 240 : cs <= 256 ? (cs + 7) / 8 * 8 : (cs + 63) / 64 * 64;
         // voxels per lane.  Measured on MI355X at 256^3 x 64 (profiles/): one voxel per lane (dword loads, 93 VGPRs,
         // 5 waves/SIMD) reaches 5.7 TB/s; 2 per lane (196 VGPRs, 2 waves/SIMD) 4.9 TB/s; 4 per lane 3.4 TB/s --
         // occupancy, not load width, is what keeps HBM busy here.  CRF_PEARSON_VPT overrides for tuning experiments.
@@ -487,6 +519,8 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
                 case 160: launch_reg_vpt<160>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 192: launch_reg_vpt<192>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 224: launch_reg_vpt<224>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 240: launch_reg_vpt<240>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
+                case 248: launch_reg_vpt<248>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 256: launch_reg_vpt<256>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 case 320: launch_reg_vpt<320>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
                 default: launch_reg_vpt<384>(vpt, d_members, d_prep, d_out, blocks, num_voxels, cs, s); break;
