@@ -426,6 +426,19 @@ void launch_symmetric(const float* const* mx, const float* const* my, int cs, si
                       hipStream_t s) {
     constexpr int kMinWaves = CS_PAD <= 32 ? 4 : (CS_PAD <= 64 ? 2 : 1);
     const unsigned blocks = unsigned((num_voxels + 255) / 256);
+    // 2 * CS_PAD values per lane.  Two waves under a 256-register cap pay off at 96 (90 members: 2.55 -> 2.04 ms) but
+    // not with the 72-670 B of scratch of the 112 / 128 instantiations (128 members: 3.92 -> 5.09 ms)
+    if constexpr (CS_PAD == 96) {
+        if (env_int("CRF_PEARSON_WAVES", 2) == 2) {
+            if (cs == CS_PAD)
+                hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, true, 2>), dim3(blocks), dim3(256), 0, s, mx, my,
+                                   d_out, uint32_t(num_voxels), cs);
+            else
+                hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, false, 2>), dim3(blocks), dim3(256), 0, s, mx, my,
+                                   d_out, uint32_t(num_voxels), cs);
+            return;
+        }
+    }
     if (cs == CS_PAD)
         hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, true, kMinWaves>), dim3(blocks), dim3(256), 0, s, mx, my,
                            d_out, uint32_t(num_voxels), cs);
