@@ -712,13 +712,20 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
 
 int crf_compute_device(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
                        void* stream) {
+    int rc;
     if (p && p->prepared_slot != 0) {
         if (p->prepared_slot < 0 || p->prepared_slot > CRF_PREPARED_SLOTS)
             return fail(c, CRF_ERR_ARGUMENT, fmt("prepared_slot %d outside [0,%d]", p->prepared_slot, CRF_PREPARED_SLOTS));
         if (c && !c->d_prep_slots) return fail(c, CRF_ERR_STATE, "prepared_slot given but crf_prepare_device was never called");
-        return compute_impl(c, p, nullptr, device_out, stream, 2u, p->prepared_slot - 1);
+        rc = compute_impl(c, p, nullptr, device_out, stream, 2u, p->prepared_slot - 1);
+    } else {
+        rc = compute_impl(c, p, device_reference_values, device_out, stream, 3u, -1);
     }
-    return compute_impl(c, p, device_reference_values, device_out, stream, 3u, -1);
+    if (rc == CRF_OK && (p->flags & CRF_FLAG_ABSOLUTE_VALUE)) {  // opt-in: what the reference's accelerator paths do
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+        CRF_HIP(c, crf::launch_abs(static_cast<float*>(device_out), c->num_voxels, s));
+    }
+    return rc;
 }
 
 int crf_prepare_device(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream) {

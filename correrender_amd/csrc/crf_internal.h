@@ -59,6 +59,7 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
                           float* d_prep, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                           LaunchInfo* info);
 hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s);
+hipError_t launch_abs(float* d_out, size_t n, hipStream_t s);  // in place |.| (CRF_FLAG_ABSOLUTE_VALUE on a field)
 
 // ---- kernels_rank.hip (Spearman, Kendall) ---------------------------------------------------------------
 // d_todo: num_voxels + 1 uint32 (count, then voxel indices) used by the split-sort kernels (64 < cs <= 128) to defer

@@ -414,6 +414,17 @@ int env_int(const char* name, int fallback) {
 
 }  // namespace
 
+__global__ void abs_kernel(float* __restrict__ out, size_t n) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fabsf(out[i]);  // NaN stays NaN
+}
+
+hipError_t launch_abs(float* d_out, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(abs_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill(float* d_out, size_t n, float value, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_out, n, value);

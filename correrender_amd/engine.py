@@ -192,19 +192,22 @@ class CorrField:
         return minmax_ref, minmax_query
 
     @staticmethod
-    def _mode_flags(symmetric, reference_from_secondary):
+    def _mode_flags(symmetric, reference_from_secondary, absolute_value=False):
+        extra = FLAG_ABSOLUTE_VALUE if absolute_value else 0
         if symmetric:
-            return FLAG_SYMMETRIC, "symmetric"
+            return FLAG_SYMMETRIC | extra, "symmetric"
         if reference_from_secondary:
-            return FLAG_REFERENCE_FROM_SECONDARY, "separate"
-        return 0, "single"
+            return FLAG_REFERENCE_FROM_SECONDARY | extra, "separate"
+        return extra, "single"
 
     def compute(self, measure, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
-                minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False) -> np.ndarray:
+                minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False,
+                absolute_value=False) -> np.ndarray:
         """Synchronous evaluation to a host array of shape (zs, ys, xs) -- calculateCpu(t, e, buffer).
         symmetric: SEPARATE_SYMMETRIC field mode (primary vs secondary members at every voxel);
-        reference_from_secondary: SEPARATE field mode (reference vector = secondary members at `ref`)."""
-        flags, mode = self._mode_flags(symmetric, reference_from_secondary)
+        reference_from_secondary: SEPARATE field mode (reference vector = secondary members at `ref`);
+        absolute_value: opt-in |.| of the field (the reference's CPU path never applies it)."""
+        flags, mode = self._mode_flags(symmetric, reference_from_secondary, absolute_value)
         minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
                                reference_values, flags)
@@ -216,10 +219,11 @@ class CorrField:
 
     def compute_device(self, measure, out, ref=None, *, device_reference=None, stream: int = 0, k=None,
                        kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None,
-                       reference_values=None, symmetric=False, reference_from_secondary=False, prepared_slot=None):
+                       reference_values=None, symmetric=False, reference_from_secondary=False, prepared_slot=None,
+                       absolute_value=False):
         """Asynchronous, stream-ordered evaluation into a CUDA float32 tensor `out` of xs*ys*zs elements.
         prepared_slot: use the reference-side tables prepare_device() left in that slot (no reference vector is read)."""
-        flags, mode = self._mode_flags(symmetric, reference_from_secondary)
+        flags, mode = self._mode_flags(symmetric, reference_from_secondary, absolute_value)
         minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, mode)
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
                                reference_values, flags)

@@ -75,8 +75,10 @@ typedef struct crf_params {
     int32_t reserved[2];             /* must be 0 */
 } crf_params;
 
-/* useAbsoluteCorrelationMeasure of the pair-request path (HEBChartCorrelation.cpp:583-585).  The full-grid path ignores
- * calculate_absolute_value on the CPU exactly like the reference (CorrelationCalculator.cpp:1662-1664). */
+/* |.| of the result.  Pair requests: useAbsoluteCorrelationMeasure (HEBChartCorrelation.cpp:583-585).  Full-grid
+ * evaluations: OPT-IN -- the reference's calculateCpu ignores calculate_absolute_value (it is a shader define of the
+ * accelerator paths only, CorrelationCalculator.cpp:1662-1664), so the C++ adapter never sets the flag; a caller that
+ * wants the accelerator paths' behaviour sets it and gets |value| (NaN stays NaN). */
 #define CRF_FLAG_ABSOLUTE_VALUE 1
 /* CorrelationFieldMode::SEPARATE_SYMMETRIC (CorrelationCalculator.hpp:59-64): crf_compute[_device] evaluate, at every
  * voxel v, the measure between X[c] = member_c[v] (the reference field = the primary members) and Y[c] =

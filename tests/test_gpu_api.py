@@ -161,3 +161,15 @@ def test_prepared_slots_match_inline_preparation(measure, cs):
             eng.prepare_device(measure, 64, device_reference=refs[0], stream=stream, **kw)
     finally:
         eng.close()
+
+
+def test_absolute_value_is_opt_in(engine):
+    ens = synth.box_ensemble(12, 10, 6, 16, seed=3)
+    ens[2, 1, 1, 1] = np.nan
+    engine.set_grid(12, 10, 6, 16)
+    engine.upload_members(ens)
+    plain = engine.compute(Measure.KENDALL, (3, 3, 3))
+    absd = engine.compute(Measure.KENDALL, (3, 3, 3), absolute_value=True)
+    assert (plain < 0).any()
+    np.testing.assert_array_equal(absd, np.abs(plain))      # NaN stays NaN
+    assert np.isnan(absd.reshape(6, 10, 12)[1, 1, 1])
