@@ -520,6 +520,8 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
                 case 1: CRF_VARIANT(4, 256, false); break;  // temporal (default-policy) loads
                 case 2: CRF_VARIANT(2, 512, true); break;   // 512-thread blocks
                 case 3: CRF_VARIANT(6, 256, true); break;   // register cap for 6 waves/SIMD
+                case 4: CRF_VARIANT(4, 128, true); break;   // 128-thread blocks
+                case 5: CRF_VARIANT(4, 64, true); break;    // one wave per block
                 default: CRF_VARIANT(4, 256, true); break;
             }
 #undef CRF_VARIANT
