@@ -111,6 +111,13 @@ struct SortNet<32> {
     }
 };
 template <>
+struct SortNet<48> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[48]) {
+#define CRF_SORTNET_N 48
+#include "sortnet.inc"
+    }
+};
+template <>
 struct SortNet<64> {
     static __device__ __forceinline__ void sort(composite_t (&a)[64]) {
 #define CRF_SORTNET_N 64

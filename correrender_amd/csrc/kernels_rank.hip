@@ -343,14 +343,16 @@ __device__ __forceinline__ void load_chunk(composite_t (&a)[CH], const float* co
 }
 
 // CH < cs <= 2*CH (CH = 64: the 65..128 member kernel; CH = 32: 33..64 members)
-template <int CH, bool EXACT, int MIN_WAVES>
+// CHB: size of chunk B's sorting network (16, 32, 48 or 64, <= CH): CH < cs <= CH + CHB.  A cs of 72 thus sorts 64 + 16
+// values instead of 64 + 64.  NPAD = member-count padding of the preparation tables (pearson_tail works on CH + CHB).
+template <int CH, bool EXACT, int MIN_WAVES, int CHB = CH>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const float* const* __restrict__ members,
                                                                        const float* __restrict__ prep,
                                                                        float* __restrict__ out, size_t num_voxels,
                                                                        int cs, uint32_t* __restrict__ todo) {
     __shared__ uint32_t lds[CH * 64];   // phase 1-3: sorted keys of chunk A [q][lane]; afterwards positions + histogram
     __shared__ uint8_t slotA[CH * 64];  // slot (0..CH-1) of the q-th smallest element of chunk A, [q][lane]
-    static_assert(2 * CH * 64 + (CH + 1) * 64 <= CH * 64 * 4, "positions + histogram must fit in the key array");
+    static_assert((CH + CHB) * 64 + (CH + 1) * 64 <= CH * 64 * 4 && CHB <= CH, "positions + histogram must fit in the key array");
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const bool active = v < num_voxels;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     const int nB = cs - CH;
     bool is_nan = false;
     uint32_t tie_min = 0xFFFFFFFFu;  // min over compared key pairs of (k1 ^ k2): 0 iff the voxel has a tie
-    uint32_t infoB[CH];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
+    uint32_t infoB[CHB];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
     {
         composite_t a[CH];
         load_chunk<CH, true, false>(a, members, nullptr, 0, cs, bytes, byte_offset);
@@ -381,20 +383,20 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     uint32_t byte_offset_b = byte_offset;
     order_after(tie_min, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
     {
-        composite_t b[CH];
-        load_chunk<CH, EXACT, false>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
+        composite_t b[CHB];
+        load_chunk<CHB, EXACT, false>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<CH>::sort(b);
+        SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int p = 0; p < CH; p++) {
+        for (int p = 0; p < CHB; p++) {
             infoB[p] = 0u;
-            if (EXACT || p < nB) {
+            if (EXACT || p < nB) {  // (a branch-free form of this loop was measured 20-45 % slower: scratch)
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CH - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CHB - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
                 prev = key;
                 const uint32_t less = lower_bound_col<CH>(&lds[lane], key, tie_min);  // #{A < b_p}, 0..CH
                 infoB[p] = less | ((composite_low(b[p]) & 0xFFu) << 8);
@@ -404,11 +406,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     __builtin_amdgcn_sched_barrier(0);
     // LDS is re-used from here on (this lane's binary searches are complete; LDS operations of a wave stay in order)
     uint8_t* pos_of = reinterpret_cast<uint8_t*>(lds);  // [slot 0..2CH-1][lane]: 0-based position in the union
-    uint8_t* hist = pos_of + 2 * CH * 64;               // [0..CH][lane]: #{b : #{A < b} == t}
+    uint8_t* hist = pos_of + (CH + CHB) * 64;               // [0..CH][lane]: #{b : #{A < b} == t}
 #pragma unroll
     for (int t = 0; t <= CH; t++) hist[t * 64 + lane] = 0;
 #pragma unroll
-    for (int p = 0; p < CH; p++) {
+    for (int p = 0; p < CHB; p++) {
         if (EXACT || p < nB) {
             const uint32_t less = infoB[p] & 0xFFu;
             const uint32_t slot = infoB[p] >> 8;
@@ -424,10 +426,10 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         pos_of[uint32_t(slotA[q * 64 + lane]) * 64 + lane] = uint8_t(uint32_t(q) + below);
     }
     __builtin_amdgcn_sched_barrier(0);
-    float r[2 * CH];
+    float r[CH + CHB];
 #pragma unroll
-    for (int e = 0; e < 2 * CH; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
-    float res = pearson_tail<2 * CH, EXACT>(r, prep, cs);
+    for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
+    float res = pearson_tail<CH + CHB, EXACT>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
         if (tie_min == 0u && !is_nan) {
@@ -455,7 +457,8 @@ __device__ __forceinline__ int32_t chunk_inversions(const composite_t (&a)[CH], 
     return inv;
 }
 
-template <int CH, bool EXACT, int MIN_WAVES>
+// CHB, NPAD: see spearman_split_kernel; the preparation tables use the stride NPAD = pad_pow2(cs)
+template <int CH, bool EXACT, int MIN_WAVES, int CHB = CH, int NPAD = 2 * CH>
 __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const float* const* __restrict__ members,
                                                                       const int* __restrict__ prep,
                                                                       float* __restrict__ out, size_t num_voxels,
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
     const int nB = cs - CH;
     // prep layout of launch_kendall_prep with n_pad = 2*CH; x-tie groups may straddle the chunks: monolithic kernel
-    const bool x_ties = prep[2 * (2 * CH) + 1] != 0;
+    const bool x_ties = prep[2 * NPAD + 1] != 0;
     if (x_ties) {
         if (active) todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         return;
@@ -498,29 +501,29 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
     order_after(discordant, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
     order_after(tie_min, byte_offset_b);
     {
-        composite_t b[CH];
-        load_chunk<CH, EXACT, true>(b, members, prep, CH, cs, bytes, byte_offset_b);
+        composite_t b[CHB];
+        load_chunk<CHB, EXACT, true>(b, members, prep, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
-        SortNet<CH>::sort(b);
+        SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
-        for (int p = 0; p < CH; p++) {
+        for (int p = 0; p < CHB; p++) {
             if (EXACT || p < nB) {
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CH - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CHB - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
                 prev = key;
                 // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
                 discordant += CH - int32_t(lower_bound_col<CH>(&keysA[lane], key, tie_min));
             }
         }
-        discordant += chunk_inversions<CH>(b, nB, EXACT);
+        discordant += chunk_inversions<CHB>(b, nB, EXACT);
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
-    const int32_t n1 = prep[2 * (2 * CH)];  // 0 here
+    const int32_t n1 = prep[2 * NPAD];  // 0 here
     const int32_t numerator = n0 - n1 - 2 * discordant;  // n2 = 0: no ties in y
     const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
     float res = float(numerator) / denominator;
@@ -579,6 +582,30 @@ void launch_kendall_n(const float* const* d_members, const int* d_prep, float* d
                            d_out, num_voxels, cs, todo);
 }
 
+// split-sort launchers: chunk A = CH members, chunk B sorted by a CHB-network (CH < cs <= CH + CHB)
+template <int CH, int CHB, int WAVES>
+void launch_spearman_split(bool exact, const float* const* d_members, const float* d_prep, float* d_out,
+                           size_t num_voxels, int cs, hipStream_t s, uint32_t* d_todo) {
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    if (exact && cs == CH + CHB)
+        hipLaunchKernelGGL((spearman_split_kernel<CH, true, WAVES, CHB>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
+                           d_out, num_voxels, cs, d_todo);
+    else
+        hipLaunchKernelGGL((spearman_split_kernel<CH, false, WAVES, CHB>), dim3(blocks), dim3(64), 0, s, d_members,
+                           d_prep, d_out, num_voxels, cs, d_todo);
+}
+template <int CH, int CHB, int WAVES>
+void launch_kendall_split(bool exact, const float* const* d_members, const int* d_prep, float* d_out, size_t num_voxels,
+                          int cs, hipStream_t s, uint32_t* d_todo) {
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    if (exact && cs == CH + CHB)
+        hipLaunchKernelGGL((kendall_split_kernel<CH, true, WAVES, CHB, 2 * CH>), dim3(blocks), dim3(64), 0, s, d_members,
+                           d_prep, d_out, num_voxels, cs, d_todo);
+    else
+        hipLaunchKernelGGL((kendall_split_kernel<CH, false, WAVES, CHB, 2 * CH>), dim3(blocks), dim3(64), 0, s, d_members,
+                           d_prep, d_out, num_voxels, cs, d_todo);
+}
+
 int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
 
 int env_int(const char* name, int fallback) {
@@ -620,6 +647,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     }
     if (ref.prepare()) launch_spearman_prep(ref, d_members, cs, d_prep, s);
     if (!ref.run()) return hipGetLastError();
+    const bool narrow_b = env_int("CRF_RANK_NARROW_B", 1) != 0;  // size chunk B's network to the member count (tuning: 0)
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -646,13 +674,11 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             // cs = 48: monolithic guarded 5.26 ms vs split 1.65 ms; cs = 40: 5.45 ms vs 1.43 ms
             if (d_todo && cs > 32 && (cs < 64 || env_split64())) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
-                const unsigned blocks = unsigned((num_voxels + 63) / 64);
-                if (cs == 64 && env_exact() && getenv("CRF_RANK_EXACT"))
-                    hipLaunchKernelGGL((spearman_split_kernel<32, true, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       d_prep, d_out, num_voxels, cs, d_todo);
+                const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
+                if (cs <= 48 && narrow_b)  // chunk B sorted by a 16-network
+                    launch_spearman_split<32, 16, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
-                    hipLaunchKernelGGL((spearman_split_kernel<32, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       d_prep, d_out, num_voxels, cs, d_todo);
+                    launch_spearman_split<32, 32, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 split = true;
                 break;
@@ -668,13 +694,14 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             // monolithic 7.5 ms / 19 ms
             if (d_todo && env_waves(2) != 0) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
-                const unsigned blocks = unsigned((num_voxels + 63) / 64);
-                if (cs == 128 && env_exact())
-                    hipLaunchKernelGGL((spearman_split_kernel<64, true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       d_prep, d_out, num_voxels, cs, d_todo);
+                if (cs <= 80 && narrow_b)
+                    launch_spearman_split<64, 16, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 96 && narrow_b)
+                    launch_spearman_split<64, 32, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 112 && narrow_b)  // merge-exchange networks exist for any size: 48 for chunk B
+                    launch_spearman_split<64, 48, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
-                    hipLaunchKernelGGL((spearman_split_kernel<64, false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       d_prep, d_out, num_voxels, cs, d_todo);
+                    launch_spearman_split<64, 64, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
                 split = true;
             } else {
@@ -703,6 +730,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     int* prep = reinterpret_cast<int*>(d_prep);
     if (ref.prepare()) launch_kendall_prep(ref, d_members, cs, n_pad, prep, s);
     if (!ref.run()) return hipGetLastError();
+    const bool narrow_b = env_int("CRF_RANK_NARROW_B", 1) != 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
@@ -729,13 +757,11 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
             // cs = 40: 1.05 vs 4.12 ms.  CRF_RANK_SPLIT64=0 selects the monolithic kernel.
             if (d_todo && cs > 32 && env_split64_default_on()) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
-                const unsigned blocks = unsigned((num_voxels + 63) / 64);
-                if (cs == 64 && env_exact() && getenv("CRF_RANK_EXACT"))
-                    hipLaunchKernelGGL((kendall_split_kernel<32, true, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       prep, d_out, num_voxels, cs, d_todo);
+                const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
+                if (cs <= 48 && narrow_b)
+                    launch_kendall_split<32, 16, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
-                    hipLaunchKernelGGL((kendall_split_kernel<32, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       prep, d_out, num_voxels, cs, d_todo);
+                    launch_kendall_split<32, 32, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 launch_kendall_n<64, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 split = true;
                 break;
@@ -749,15 +775,17 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
         default:
             if (d_todo && env_waves(2) != 0) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
-                const unsigned blocks = unsigned((num_voxels + 63) / 64);
                 // the guarded instantiation compiles to 226 VGPRs without scratch and is the fastest for every cs
                 // (4.8 ms at 256^3 x 128 vs 12.8 ms unguarded, 13.9-27.7 ms monolithic)
-                if (cs == 128 && env_exact() && getenv("CRF_RANK_EXACT"))
-                    hipLaunchKernelGGL((kendall_split_kernel<64, true, 2>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       prep, d_out, num_voxels, cs, d_todo);
+                const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
+                if (cs <= 80 && narrow_b)
+                    launch_kendall_split<64, 16, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 96 && narrow_b)
+                    launch_kendall_split<64, 32, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 112 && narrow_b)
+                    launch_kendall_split<64, 48, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
-                    hipLaunchKernelGGL((kendall_split_kernel<64, false, 2>), dim3(blocks), dim3(64), 0, s, d_members,
-                                       prep, d_out, num_voxels, cs, d_todo);
+                    launch_kendall_split<64, 64, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
                 split = true;
             } else {
