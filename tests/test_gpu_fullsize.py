@@ -165,3 +165,33 @@ def test_config5_pearson_slab_of_1024cubed_256_members(engine, oracle):
     finally:
         del members
         torch.cuda.empty_cache()
+
+
+def test_ragged_million_voxels_with_many_tied_voxels(engine, oracle):
+    """101 x 103 x 97 voxels (no power of two anywhere, ragged last blocks), 50 members, ~3 % of the voxels carry ties
+    (so the split-sort kernels defer tens of thousands of voxels to the tie list), a NaN here and there."""
+    xs, ys, zs, cs = 101, 103, 97, 50
+    rng = np.random.default_rng(2026)
+    ens = rng.standard_normal((cs, zs, ys, xs)).astype(np.float32)
+    flat = ens.reshape(cs, -1)
+    n = flat.shape[1]
+    tied = rng.choice(n, size=n // 33, replace=False)
+    flat[:, tied] = np.round(flat[:, tied] * 2) / 2
+    nan_vox = rng.choice(n, size=50, replace=False)
+    flat[rng.integers(0, cs, 50), nan_vox] = np.nan
+    ref_idx = int(tied[0])                                        # a reference vector with ties of its own
+    while np.isnan(flat[:, ref_idx]).any():
+        ref_idx += 1
+    ref_xyz = (ref_idx % xs, (ref_idx // xs) % ys, ref_idx // (xs * ys))
+    ref_values = flat[:, ref_idx].copy()
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    for m, om in ((Measure.PEARSON, oracle_lib.PEARSON), (Measure.SPEARMAN, oracle_lib.SPEARMAN),
+                  (Measure.KENDALL, oracle_lib.KENDALL)):
+        assert_bit_exact(engine.compute(m, ref_xyz), oracle.field(om, ens, ref_values), f"{m.name} ragged 1M")
+    finite = flat[np.isfinite(flat)]
+    mm = (float(finite.min()), float(finite.max()))
+    assert_close(engine.compute(Measure.MUTUAL_INFORMATION_BINNED, ref_xyz, num_bins=80, minmax_ref=mm, minmax_query=mm),
+                 oracle.field(oracle_lib.MI_BINNED, ens, ref_values, num_bins=80, minmax_ref=mm), "binned ragged 1M")
+    assert_close(engine.compute(Measure.MUTUAL_INFORMATION_KRASKOV, ref_xyz, k=3),
+                 oracle.field(oracle_lib.MI_KRASKOV, ens, ref_values, k=3), "kraskov ragged 1M")
