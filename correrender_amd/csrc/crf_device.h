@@ -111,9 +111,30 @@ struct SortNet<32> {
     }
 };
 template <>
+struct SortNet<24> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[24]) {
+#define CRF_SORTNET_N 24
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet<40> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[40]) {
+#define CRF_SORTNET_N 40
+#include "sortnet.inc"
+    }
+};
+template <>
 struct SortNet<48> {
     static __device__ __forceinline__ void sort(composite_t (&a)[48]) {
 #define CRF_SORTNET_N 48
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet<56> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[56]) {
+#define CRF_SORTNET_N 56
 #include "sortnet.inc"
     }
 };

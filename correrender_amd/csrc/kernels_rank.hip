@@ -343,7 +343,7 @@ __device__ __forceinline__ void load_chunk(composite_t (&a)[CH], const float* co
 }
 
 // CH < cs <= 2*CH (CH = 64: the 65..128 member kernel; CH = 32: 33..64 members)
-// CHB: size of chunk B's sorting network (16, 32, 48 or 64, <= CH): CH < cs <= CH + CHB.  A cs of 72 thus sorts 64 + 16
+// CHB: size of chunk B's sorting network (a multiple of 8, <= CH): CH < cs <= CH + CHB.  A cs of 72 thus sorts 64 + 16
 // values instead of 64 + 64.  NPAD = member-count padding of the preparation tables (pearson_tail works on CH + CHB).
 template <int CH, bool EXACT, int MIN_WAVES, int CHB = CH>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const float* const* __restrict__ members,
@@ -677,6 +677,8 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                 const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
                 if (cs <= 48 && narrow_b)  // chunk B sorted by a 16-network
                     launch_spearman_split<32, 16, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 56 && narrow_b)
+                    launch_spearman_split<32, 24, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_spearman_split<32, 32, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
@@ -698,8 +700,12 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                     launch_spearman_split<64, 16, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else if (cs <= 96 && narrow_b)
                     launch_spearman_split<64, 32, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 112 && narrow_b)  // merge-exchange networks exist for any size: 48 for chunk B
+                else if (cs <= 104 && narrow_b)  // merge-exchange networks exist for any size
+                    launch_spearman_split<64, 40, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 112 && narrow_b)
                     launch_spearman_split<64, 48, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 120 && narrow_b)
+                    launch_spearman_split<64, 56, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_spearman_split<64, 64, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
@@ -760,6 +766,8 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                 const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
                 if (cs <= 48 && narrow_b)
                     launch_kendall_split<32, 16, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 56 && narrow_b)
+                    launch_kendall_split<32, 24, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_kendall_split<32, 32, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 launch_kendall_n<64, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);
@@ -782,8 +790,12 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                     launch_kendall_split<64, 16, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else if (cs <= 96 && narrow_b)
                     launch_kendall_split<64, 32, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 104 && narrow_b)
+                    launch_kendall_split<64, 40, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else if (cs <= 112 && narrow_b)
                     launch_kendall_split<64, 48, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 120 && narrow_b)
+                    launch_kendall_split<64, 56, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_kendall_split<64, 64, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 launch_kendall_n<128, 1>(d_members, prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
