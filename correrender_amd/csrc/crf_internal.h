@@ -71,7 +71,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                           float* d_prep, uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin,
                           hipEvent_t ev_end, LaunchInfo* info);
 
-// ---- kernels_mi.hip (binned, Kraskov) -------------------------------------------------------------------
+// ---- kernels_binned.hip / kernels_kraskov.hip -------------------------------------------------------------------
 struct BinnedArgs {
     int num_bins;
     float min_ref, max_ref, min_query, max_query;
@@ -154,7 +154,7 @@ hipError_t launch_direct_symmetric(const float* const* d_members_x, const float*
 constexpr int kMaxSymmetricRegisterMembers = 128;
 hipError_t launch_pearson_symmetric(const float* const* d_members_ref, const float* const* d_members_query, int cs,
                                     size_t num_voxels, float* d_out, hipStream_t s);
-// preparation launchers shared with the generic path (kernels_rank.hip / kernels_mi.hip); n_pad = table stride
+// preparation launchers shared with the generic path (kernels_rank.hip / kernels_binned.hip / kernels_kraskov.hip); n_pad = table stride
 void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s);
 void launch_kendall_prep(const RefSource& ref, const float* const* d_members, int cs, int n_pad, int* d_prep,
                          hipStream_t s);

@@ -1,6 +1,6 @@
 // kernels_generic.hip -- Spearman / Kendall / binned MI / Kraskov MI for ANY member count (cs up to kMaxGenericMembers).
 //
-// The register-resident kernels (kernels_rank.hip, kernels_mi.hip) are instantiated for cs <= 128; the reference has
+// The register-resident kernels (kernels_rank.hip, kernels_binned.hip, kernels_kraskov.hip) are instantiated for cs <= 128; the reference has
 // no such limit (its own synthetic data set has 1000 members, scripts/generate_synth_box_ensembles.py:47).  These
 // kernels keep the same mapping -- one lane = one voxel -- but hold the voxel's cs values in a per-lane column
 // [member][lane] of a tile that lives in LDS when it fits and otherwise in a global workspace slice owned by the block
@@ -10,7 +10,7 @@
 //   binned    first-occurrence scan over the voxel's cell codes (the skipped-sample path of mi_binned_kernel)
 //   Kraskov   the same brute-force k-select as mi_kraskov_kernel, tile pointer instead of LDS
 // Integer cores are exact; fp32 tails use the reference's operation order; fp64 sums of the MI estimators differ from
-// the reference's order at the 1e-16 level (see kernels_mi.hip).  Throughput is secondary here: at cs = 1000 the
+// the reference's order at the 1e-16 level (see kernels_binned.hip).  Throughput is secondary here: at cs = 1000 the
 // pair loops are ~10^6 compares per voxel, ~20 ms for the reference's 128x128x32 data set.
 #include <cstdlib>
 
@@ -37,7 +37,7 @@ size_t generic_workspace_bytes(int cs, size_t num_voxels) {
     return generic > direct ? generic : direct;
 }
 
-__device__ __forceinline__ float mi_to_cc_generic(float mi);  // defined below (same map as kernels_mi.hip)
+__device__ __forceinline__ float mi_to_cc_generic(float mi);  // defined below (same map as crf_mi_device.h)
 
 // ---- per-voxel evaluators: `vals` / `aux` point at this lane's column (stride 64 elements) ------------------
 
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restr
     }
 }
 
-// glibc-compatible expf for the MI-CC map: see kernels_mi.hip (same algorithm and table).
+// glibc-compatible expf for the MI-CC map: see crf_mi_device.h (same algorithm and table).
 __device__ const uint64_t kExp2Tab32G[32] = {
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
     0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
