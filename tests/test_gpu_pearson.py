@@ -97,3 +97,23 @@ def test_pearson_device_path_matches_host_path(engine, oracle):
     want = oracle.field(oracle_lib.PEARSON, ens, ens[:, 3, 2, 1].copy())
     assert_bit_exact(out.cpu().numpy(), want, "pearson device reference")
     assert bit_identical(out.cpu().numpy(), want).all()
+
+
+@pytest.mark.parametrize("cs", [16, 64, 100, 200])
+def test_pearson_magnitude_sweep_bit_exact(engine, oracle, cs):
+    """Every voxel gets its own scale and offset over 50 decades, so the per-voxel quotient (y - mean) / sd is taken at
+    standard deviations and means on both sides of the exact-division guard (crf_device.h: sd in [2^-60, 2^60],
+    |mean| >= 2^-70) and through the plain-division path of whole waves."""
+    rng = np.random.default_rng(1000 + cs)
+    xs, ys, zs = 64, 32, 8
+    n = xs * ys * zs
+    base = rng.standard_normal((cs, n)).astype(np.float64)
+    scale = 10.0 ** rng.uniform(-25, 25, n)
+    offset = np.where(rng.random(n) < 0.5, 0.0, 10.0 ** rng.uniform(-25, 25, n) * rng.choice([-1.0, 1.0], n))
+    # a few voxels right at the guard boundaries
+    scale[:8] = [2.0 ** -60, 2.0 ** -61, 2.0 ** 60, 2.0 ** 61, 2.0 ** -59, 2.0 ** 59, 1.0, 1.0]
+    offset[:8] = [0.0, 0.0, 0.0, 0.0, 2.0 ** -70, 2.0 ** -71, 2.0 ** -70, 2.0 ** -72]
+    with np.errstate(over="ignore"):
+        ens = (base * scale + offset).astype(np.float32).reshape(cs, zs, ys, xs)
+    got, want = _run(engine, oracle, ens, (3, 2, 1))
+    assert_bit_exact(got, want, f"pearson magnitude sweep cs={cs}")
