@@ -207,7 +207,7 @@ def main():
             "config": {"workload": f"{args.measure} correlation field, {xs}x{ys}x{zs} grid x {cs} ensemble members "
                                    "(synthetic box ensemble), one moving reference point per step",
                        "grid": [xs, ys, zs], "members": cs, "measure": args.measure,
-                       "sharding": f"z-slab x{world}" + (f", reference vectors exchanged over RCCL ({LOOKAHEAD} requested points per collective)" if world > 1 else ""),
+                       "sharding": f"z-slab x{world}" + (f", reference vectors exchanged over {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} ({LOOKAHEAD} requested points per collective)" if world > 1 else ""),
                        "resident": "members and result in HBM"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
