@@ -72,6 +72,7 @@ SYMBOLS = {
     "crf_compute_set_predicate_device": (C.c_int, [_VOIDP, C.c_int, C.c_float, C.c_int, C.c_int, _VOIDP, _VOIDP]),
     "crf_compute_dkl": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "crf_compute_dkl_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
+    "crf_max_mutual_information_kraskov": (C.c_double, [C.c_int, C.c_int]),
     "crf_tiled_element_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "crf_tile_field_device": (C.c_int, [_VOIDP, _VOIDP, _VOIDP, _VOIDP]),
     "crf_set_profiling": (C.c_int, [_VOIDP, C.c_int]),

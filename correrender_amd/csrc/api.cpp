@@ -906,6 +906,16 @@ int crf_compute_dkl(crf_context* c, int estimator, int num_bins, int k, float* h
     return copy_result_to_host(c, c->d_out, host_out, c->num_voxels);
 }
 
+double crf_max_mutual_information_kraskov(int k, int cs) {
+    if (k < 1 || cs < 1) return std::numeric_limits<double>::quiet_NaN();
+    auto psi = [](int n) {
+        long double h = 0.0L;
+        for (int i = 1; i < n; i++) h += 1.0L / (long double)i;
+        return double(h - 0.577215664901532860606512090082402431L);
+    };
+    return psi(cs) - psi(k);
+}
+
 size_t crf_tiled_element_count(int xs, int ys, int zs) {
     if (xs <= 0 || ys <= 0 || zs <= 0) return 0;
     return size_t((xs + 7) / 8) * size_t((ys + 7) / 8) * size_t((zs + 3) / 4) * 256;

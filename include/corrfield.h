@@ -212,6 +212,11 @@ int crf_compute_dkl_device(crf_context* ctx, int estimator, int num_bins, int k,
 size_t crf_tiled_element_count(int xs, int ys, int zs);
 int crf_tile_field_device(crf_context* ctx, const void* device_linear, void* device_tiled, void* stream);
 
+/* Upper bound of the KSG estimate used for the colour range of the diagrams:
+ * computeMaximumMutualInformationKraskov(k, es) = psi(es) - psi(k) (MutualInformation.cpp:526-528); psi(n) = -gamma + H_{n-1}.
+ * Host-only helper, no context needed; NaN for k < 1 or cs < 1. */
+double crf_max_mutual_information_kraskov(int k, int cs);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* When enabled, every crf_compute* brackets its dominant (per-voxel) kernel with HIP events on the launch stream. */
 int crf_set_profiling(crf_context* ctx, int enabled);

@@ -66,3 +66,15 @@ def test_product_does_not_reference_the_oracle():
             assert "liboracle" not in text and "oracle_lib" not in text and "libref_corr" not in text, p
     out = subprocess.run(["ldd", str(ca.library_path())], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_host_only_helpers(oracle):
+    """Entry points that need no device: the tiled element count and the KSG colour-range bound psi(cs) - psi(k)."""
+    from correrender_amd._lib import load_library
+    lib = load_library()
+    assert lib.crf_tiled_element_count(19, 10, 6) == 3 * 2 * 2 * 256 and lib.crf_tiled_element_count(0, 1, 1) == 0
+    for k, cs in ((3, 64), (1, 2), (30, 1000)):
+        assert lib.crf_max_mutual_information_kraskov(k, cs) == oracle.digamma(cs) - oracle.digamma(k)
+    assert abs(lib.crf_max_mutual_information_kraskov(3, 64) - 3.228266) < 1e-6      # SURVEY 8(c) probe value
+    import math
+    assert math.isnan(lib.crf_max_mutual_information_kraskov(0, 64))
