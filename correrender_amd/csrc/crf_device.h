@@ -15,7 +15,10 @@ namespace crf {
 // once per evaluation and the ensemble dwarfs the 256 MiB Infinity Cache.  A member volume (or slab) is < 4 GiB
 // (checked in crf_set_grid), so the 32-bit offset and num_records suffice.
 typedef int32_t __attribute__((ext_vector_type(4))) buffer_rsrc_t;
-constexpr int kAuxNonTemporal = 2;
+#ifndef CRF_LOAD_AUX
+#define CRF_LOAD_AUX 2
+#endif
+constexpr int kAuxNonTemporal = CRF_LOAD_AUX;  // buffer-load cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
 __device__ __forceinline__ auto make_member_rsrc(const float* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), /*stride*/ short(0), int(bytes), 0x00020000);
 }
@@ -31,6 +34,9 @@ __device__ __forceinline__ float load_member_cached(const float* base, uint32_t 
 __device__ __forceinline__ float load_member_nt(const float* base, uint32_t bytes, uint32_t byte_offset) {
     return buffer_load_f32_nt(make_member_rsrc(base, bytes), byte_offset);
 }
+// Result stores of the bandwidth-bound kernels: written once, never re-read by the kernel (non-temporal)
+__device__ __forceinline__ void store_result_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
 // Offset that is out of range for every member descriptor (num_records <= 4 * 2^30): a load through it returns 0
 // without a memory request.  Padded slots of the guarded kernels select it (wave-uniform condition, one v_cndmask)
 // instead of branching around the load or re-reading a valid member.

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ensemble_stat_reg_kernel(const float* con
         }
         res = num_valid > 1 ? sqrtf(var_sum / float(num_valid - 1)) : __uint_as_float(0x7FC00000u);
     }
-    if (v0 < num_voxels) out[v0] = res;
+    if (v0 < num_voxels) store_result_nt(out + v0, res);
 }
 
 // Any member count: streaming passes (the spread re-reads the members once; mostly served by L2 / Infinity Cache).
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ensemble_stat_stream_kernel(const float* 
         }
         res = num_valid > 1 ? sqrtf(var_sum / float(num_valid - 1)) : __uint_as_float(0x7FC00000u);
     }
-    if (v0 < num_voxels) out[v0] = res;
+    if (v0 < num_voxels) store_result_nt(out + v0, res);
 }
 
 // Set predicate (SetPredicateCalculator::calculateCpu, src/Calculators/SetPredicateCalculator.cpp:154-210): count the
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void set_predicate_kernel(const float* const* 
     float res = float(count) - float(count_lower);
     if (count_lower != count_upper) res = res / (float(count_upper) - float(count_lower));
     res = res < 0.0f ? 0.0f : (1.0f < res ? 1.0f : res);  // std::clamp: -0.0 stays -0.0
-    if (v0 < num_voxels) out[v0] = res;
+    if (v0 < num_voxels) store_result_nt(out + v0, res);
 }
 
 hipError_t launch_set_predicate(const float* const* d_members, int cs, size_t num_voxels, int op, float comparison_value,
