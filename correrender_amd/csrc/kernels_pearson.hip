@@ -193,6 +193,84 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void pearson_reg_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// R + up to L members: the first R values of a voxel in registers (always members: no guards), the remaining cs - R
+// (1..L) in the lane's LDS column.  For member counts just above what fits two waves per SIMD in registers: 256
+// register values spill 120 B - 1 KB under the 256-register cap, 240 + 16 in LDS do not (16 x 1 KB per block).
+// The tail slots are handled in uniform branches (they are in LDS: no register live ranges to split).
+// ---------------------------------------------------------------------------------------------------------
+template <int R, int L, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_lds_kernel(const float* const* __restrict__ members,
+                                                                         const float* __restrict__ prep,
+                                                                         float* __restrict__ out, uint32_t num_voxels,
+                                                                         int cs) {
+    extern __shared__ float tail_dyn[];  // L rows of 256 floats (dynamic: 80 rows exceed the 64 KB static limit)
+    float(*tail)[256] = reinterpret_cast<float(*)[256]>(tail_dyn);
+    const uint32_t v0 = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t byte_offset = v0 * 4u, bytes = num_voxels * 4u;
+    const int nt = cs - R;  // members in the LDS tail, 1..L
+    float y[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) y[e] = load_member_nt(members[e], bytes, byte_offset);
+    // the tail goes straight from memory to LDS (global_load_lds: no registers, issued back to back with the loads above;
+    // the hardware writes lane l of a wave to lds_base + 4 l, i.e. the wave's own 64 consecutive floats of the row,
+    // which only this wave reads again, so the only synchronisation is its own vmcnt wait).  Lanes past the end of the
+    // grid read the last voxel instead (no descriptor bounds on this path); they store nothing.
+    const int wave_first = int(threadIdx.x) & ~63;
+    const uint32_t v_safe = v0 < num_voxels ? v0 : num_voxels - 1u;
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+        if (t < nt) {
+            typedef const float __attribute__((address_space(1)))* gptr_t;
+            typedef float __attribute__((address_space(3)))* lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(members[R + t] + v_safe), (lptr_t)&tail[t][wave_first], 4, 0,
+                                             kAuxNonTemporal);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < R; e++) meanY += invN * y[e];
+#pragma unroll
+    for (int t = 0; t < L; t++)
+        if (t < nt) meanY += invN * tail[t][threadIdx.x];
+    float varY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        const float d = y[e] - meanY;
+        y[e] = d;
+        varY += invNm1 * d * d;
+    }
+#pragma unroll
+    for (int t = 0; t < L; t++) {
+        if (t < nt) {
+            const float d = tail[t][threadIdx.x] - meanY;
+            tail[t][threadIdx.x] = d;
+            varY += invNm1 * d * d;
+        }
+    }
+    const float sdY = sqrtf(varY);
+    float r = 0.0f;
+    if (__all(exact_div_guard(meanY, sdY))) {
+        const float rcp = 1.0f / sdY;
+#pragma unroll
+        for (int e = 0; e < R; e++) r += prep[e] * exact_div(y[e], sdY, rcp);
+#pragma unroll
+        for (int t = 0; t < L; t++)
+            if (t < nt) r += prep[R + t] * exact_div(tail[t][threadIdx.x], sdY, rcp);
+    } else {
+#pragma unroll
+        for (int e = 0; e < R; e++) r += prep[e] * (y[e] / sdY);
+#pragma unroll
+        for (int t = 0; t < L; t++)
+            if (t < nt) r += prep[R + t] * (tail[t][threadIdx.x] / sdY);
+    }
+    if (v0 < num_voxels) store_result_nt(out + v0, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Symmetric field mode (CorrelationFieldMode::SEPARATE_SYMMETRIC, CorrelationMain.glsl:10-15): voxel v correlates
 // the reference field's members at v with the query field's members at v -- computePearson2 on two arrays
 // (Correlation.cpp:141-174), nothing to hoist.  2*cs loads per voxel (8*cs + 4 algorithmic bytes), both sides in
@@ -529,6 +607,38 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
 #undef CRF_VARIANT
             if (info) info->kernel_name = "pearson_reg_kernel";
             goto tail;
+        }
+        // 241..320 members: 240 values in registers + the rest in the lane's LDS column (pearson_reg_lds_kernel); measured at
+        // 512x512x128: 256 members 85 % of the HBM peak (64 % with 256 register values under the two-wave cap, 53 % at one
+        // wave), 272: 82 % (57 %), 288: 78 % (54 %), 300: 71 % (54 %), 320: 69 % (59 %).  CRF_PEARSON_LDS_TAIL=0 selects the pure register kernels.
+        if (cs > 224 && cs <= 320 && env_int("CRF_PEARSON_LDS_TAIL", 1) != 0) {
+            const size_t blocks_ = (num_voxels + 255) / 256;
+            hipError_t attr = hipSuccess;
+#define CRF_LAUNCH_REG_LDS(R_, L_)                                                                                \
+    {                                                                                                             \
+        constexpr size_t kBytes = size_t(L_) * 256 * sizeof(float);                                               \
+        if (kBytes > 64 * 1024)                                                                                   \
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&pearson_reg_lds_kernel<R_, L_, 2>),          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(kBytes));                  \
+        if (attr == hipSuccess)                                                                                   \
+            hipLaunchKernelGGL((pearson_reg_lds_kernel<R_, L_, 2>), dim3(unsigned(blocks_)), dim3(256), kBytes, s,  \
+                               d_members, d_prep, d_out, uint32_t(num_voxels), cs);                               \
+    }
+            if (cs <= 240) {
+                CRF_LAUNCH_REG_LDS(224, 16)
+            } else if (cs <= 256) {
+                CRF_LAUNCH_REG_LDS(240, 16)
+            } else if (cs <= 288) {
+                CRF_LAUNCH_REG_LDS(240, 48)
+            } else {
+                CRF_LAUNCH_REG_LDS(240, 80)  // (144 rows for 321..384 were measured: one block per CU, 31-33 % -- not kept)
+            }
+#undef CRF_LAUNCH_REG_LDS
+            if (attr == hipSuccess) {
+                covered = num_voxels;
+                if (info) info->kernel_name = "pearson_reg_lds_kernel";
+                goto tail;
+            }
         }
         const size_t per_block = size_t(256) * vpt;
         covered = num_voxels / vpt * vpt;                       // whole vectors; the descriptor bounds the last block
