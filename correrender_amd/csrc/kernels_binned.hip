@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     float res = float(mi);
     if (to_cc) res = mi_to_cc(res);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) out[v] = res;
+    if (v < num_voxels) store_result_nt(out + v, res);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64) void mi_binned_hist_kernel(const float* const* 
         float res = float(mi);
         if (to_cc) res = mi_to_cc(res);
         if (is_nan) res = __uint_as_float(0x7FC00000u);
-        if (v < num_voxels) out[v] = res;
+        if (v < num_voxels) store_result_nt(out + v, res);
     }
 }
 

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void dkl_kernel(const float* const* __restrict_
         }
         if (is_nan) res = qnan;
         if (cs == 1) res = 1.0f;
-        if (active) out[v] = res;
+        if (active) store_result_nt(out + v, res);
     }
 }
 

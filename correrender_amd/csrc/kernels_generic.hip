@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
             res = float(numerator) / denominator;
         }
         if (is_nan) res = __uint_as_float(0x7FC00000u);
-        if (v < num_voxels) out[v] = res;
+        if (v < num_voxels) store_result_nt(out + v, res);
     }
 }
 
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
         }
         if (is_nan) res = __uint_as_float(0x7FC00000u);
         if (cs == 1) res = 1.0f;
-        if (v < num_voxels) out[v] = res;
+        if (v < num_voxels) store_result_nt(out + v, res);
     }
 }
 
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restr
             }
         }
         if (is_nan) res = __uint_as_float(0x7FC00000u);
-        if (v < num_voxels) out[v] = res;
+        if (v < num_voxels) store_result_nt(out + v, res);
     }
 }
 

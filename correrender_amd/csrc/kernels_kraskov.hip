@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
     res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
     if (to_cc) res = mi_to_cc(res);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) out[v] = res;
+    if (v < num_voxels) store_result_nt(out + v, res);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
         res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
         if (to_cc) res = mi_to_cc(res);
         if (is_nan) res = __uint_as_float(0x7FC00000u);
-        if (v < num_voxels) out[v] = res;
+        if (v < num_voxels) store_result_nt(out + v, res);
     }
 }
 

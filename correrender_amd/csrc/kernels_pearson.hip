@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void pearson_stream_kernel(const float* const*
     const float sdY = sqrtf(varY);
     float r = 0.0f;
     for (int e = 0; e < cs; e++) r += prep[e] * ((members[e][v0] - meanY) / sdY);
-    out[v0] = r;
+    store_result_nt(out + v0, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------

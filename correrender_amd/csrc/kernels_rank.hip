@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     for (int e = 0; e < N; e++) r[e] = (EXACT || e < cs) ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
     float res = pearson_tail<N, EXACT>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (active) out[v] = res;
+    if (active) store_result_nt(out + v, res);
     if (todo == nullptr) break;
     }
 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2));
     float res = float(numerator) / denominator;
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (active) out[v] = res;
+    if (active) store_result_nt(out + v, res);
     if (todo == nullptr) break;
     }
 }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         if (tie_min == 0u && !is_nan) {
             todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         } else {
-            out[v] = res;
+            store_result_nt(out + v, res);
         }
     }
 }
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         if (tie_min == 0u && !is_nan) {
             todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         } else {
-            out[v] = res;
+            store_result_nt(out + v, res);
         }
     }
 }
