@@ -103,6 +103,13 @@ __device__ __forceinline__ composite_t composite_or_low(composite_t c, uint32_t 
 template <int N>
 struct SortNet;
 template <>
+struct SortNet<8> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[8]) {
+#define CRF_SORTNET_N 8
+#include "sortnet.inc"
+    }
+};
+template <>
 struct SortNet<16> {
     static __device__ __forceinline__ void sort(composite_t (&a)[16]) {
 #define CRF_SORTNET_N 16
@@ -246,7 +253,8 @@ __device__ __forceinline__ float exact_div(float a, float b, float rcp) {
 
 // The voxel side of computePearson2<float> (Correlation.cpp:141-174) for one lane: y[0..cs) in registers, a_e =
 // invNm1 * ((x_e - meanX) / sdX) prepared once per evaluation.  Sequential fp32, no contraction.
-template <int N, bool EXACT>
+// SURE: slots 0..SURE-1 are members whatever cs is (the caller's contract), so only the slots behind them are guarded.
+template <int N, bool EXACT, int SURE = 0>
 __device__ __forceinline__ float pearson_tail(float (&y)[N], const float* __restrict__ prep_a, int cs) {
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -259,7 +267,7 @@ __device__ __forceinline__ float pearson_tail(float (&y)[N], const float* __rest
     float varY = 0.0f;
 #pragma unroll
     for (int e = 0; e < N; e++) {
-        const float d = (EXACT || e < cs) ? y[e] - meanY : 0.0f;
+        const float d = (EXACT || e < SURE || e < cs) ? y[e] - meanY : 0.0f;
         y[e] = d;
         varY += invNm1 * d * d;
     }
@@ -271,7 +279,7 @@ __device__ __forceinline__ float pearson_tail(float (&y)[N], const float* __rest
         for (int e = 0; e < N; e++) r += prep_a[e] * exact_div(y[e], sdY, rcp);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; e++) r += prep_a[e] * ((EXACT || e < cs) ? y[e] / sdY : 0.0f);
+        for (int e = 0; e < N; e++) r += prep_a[e] * ((EXACT || e < SURE || e < cs) ? y[e] / sdY : 0.0f);
     }
     return r;
 }

@@ -323,14 +323,15 @@ __device__ __forceinline__ uint32_t lower_bound_col(const uint32_t* col, uint32_
 }
 
 // loads slots base..base+CH-1 of the lane's voxel as composites (low word = slot - base), pads beyond cs
-template <int CH, bool EXACT, bool PERMUTED>
+// SURE: the first SURE slots of the chunk are members whatever cs is (caller's contract): no guard on them
+template <int CH, bool EXACT, bool PERMUTED, int SURE = 0>
 __device__ __forceinline__ void load_chunk(composite_t (&a)[CH], const float* const* __restrict__ members,
                                            const int* __restrict__ perm, int base, int cs, uint32_t bytes,
                                            uint32_t byte_offset) {
     float y[CH];  // all loads first (slots past cs: out-of-range offset, no memory request), then the conversion
 #pragma unroll
     for (int e = 0; e < CH; e++) {
-        const bool real = EXACT || base + e < cs;
+        const bool real = EXACT || e < SURE || base + e < cs;
         const int slot = real ? base + e : cs - 1;
         y[e] = load_member_nt(PERMUTED ? members[perm[slot]] : members[slot], bytes,
                               real ? byte_offset : kOutOfRangeOffset);
@@ -338,13 +339,16 @@ __device__ __forceinline__ void load_chunk(composite_t (&a)[CH], const float* co
 #pragma unroll
     for (int e = 0; e < CH; e++) {
         const float yc = y[e] + 0.0f;
-        a[e] = make_composite((EXACT || base + e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
+        a[e] = make_composite((EXACT || e < SURE || base + e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
     }
 }
 
 // CH < cs <= 2*CH (CH = 64: the 65..128 member kernel; CH = 32: 33..64 members)
-// CHB: size of chunk B's sorting network (a multiple of 8, <= CH): CH < cs <= CH + CHB.  A cs of 72 thus sorts 64 + 16
+// CHB: size of chunk B's sorting network (a multiple of 8, <= CH): CH < cs <= CH + CHB.  A cs of 72 thus sorts 64 + 8
 // values instead of 64 + 64.  NPAD = member-count padding of the preparation tables (pearson_tail works on CH + CHB).
+// The Spearman kernel requires the TIGHT network, CH + CHB - 8 < cs: only the last 8 slots of chunk B can be pads, so
+// the per-element guards (wave-uniform branches that keep the binary searches of different elements from overlapping:
+// +35-45 % at cs = 88 / 100) are compile-time true for all the others.
 template <int CH, bool EXACT, int MIN_WAVES, int CHB = CH>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const float* const* __restrict__ members,
                                                                        const float* __restrict__ prep,
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     const bool active = v < num_voxels;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
     const int nB = cs - CH;
+    constexpr int SURE_B = CHB - 8;  // chunk B slots that are members for every cs of this instantiation
     bool is_nan = false;
     uint32_t tie_min = 0xFFFFFFFFu;  // min over compared key pairs of (k1 ^ k2): 0 iff the voxel has a tie
     uint32_t infoB[CHB];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     order_after(tie_min, byte_offset_b);  // chunk B is not touched before chunk A is fully consumed
     {
         composite_t b[CHB];
-        load_chunk<CHB, EXACT, false>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
+        load_chunk<CHB, EXACT, false, SURE_B>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
@@ -392,11 +397,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
 #pragma unroll
         for (int p = 0; p < CHB; p++) {
             infoB[p] = 0u;
-            if (EXACT || p < nB) {  // (a branch-free form of this loop was measured 20-45 % slower: scratch)
+            if (EXACT || p < SURE_B || p < nB) {  // (a branch-free form of this loop was measured 20-45 % slower: scratch)
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CHB - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CHB - 1 : (p >= SURE_B && p == nB - 1)) is_nan |= key > 0xFF800000u;
                 prev = key;
                 const uint32_t less = lower_bound_col<CH>(&lds[lane], key, tie_min);  // #{A < b_p}, 0..CH
                 infoB[p] = less | ((composite_low(b[p]) & 0xFFu) << 8);
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     for (int t = 0; t <= CH; t++) hist[t * 64 + lane] = 0;
 #pragma unroll
     for (int p = 0; p < CHB; p++) {
-        if (EXACT || p < nB) {
+        if (EXACT || p < SURE_B || p < nB) {
             const uint32_t less = infoB[p] & 0xFFu;
             const uint32_t slot = infoB[p] >> 8;
             const uint32_t h = hist[less * 64 + lane];
@@ -428,8 +433,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     __builtin_amdgcn_sched_barrier(0);
     float r[CH + CHB];
 #pragma unroll
-    for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
-    float res = pearson_tail<CH + CHB, EXACT>(r, prep, cs);
+    for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < CH + SURE_B || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
+    float res = pearson_tail<CH + CHB, EXACT, CH + SURE_B>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
         if (tie_min == 0u && !is_nan) {
@@ -441,13 +446,13 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
 }
 
 // discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..CH-1), one 64-bit "seen" set
-template <int CH>
+template <int CH, int SURE = 0>
 __device__ __forceinline__ int32_t chunk_inversions(const composite_t (&a)[CH], int count, bool exact) {
     uint64_t seen = 0ull;
     int32_t inv = 0;
 #pragma unroll
     for (int p = 0; p < CH; p++) {
-        if (exact || p < count) {
+        if (exact || p < SURE || p < count) {
             uint32_t slot = composite_low(a[p]) & 0xFFu;
             if ((p & 3) == 0) order_after(slot, seen);  // keep the mask computations from being hoisted en bloc
             inv += __popcll(seen & (0xFFFFFFFFFFFFFFFEull << slot));  // already-seen slots above this one
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
     const bool active = v < num_voxels;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
     const int nB = cs - CH;
+    constexpr int SURE_B = CHB - 8;  // CH + CHB - 8 < cs (see spearman_split_kernel)
     // prep layout of launch_kendall_prep with n_pad = 2*CH; x-tie groups may straddle the chunks: monolithic kernel
     const bool x_ties = prep[2 * NPAD + 1] != 0;
     if (x_ties) {
@@ -502,24 +508,24 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
     order_after(tie_min, byte_offset_b);
     {
         composite_t b[CHB];
-        load_chunk<CHB, EXACT, true>(b, members, prep, CH, cs, bytes, byte_offset_b);
+        load_chunk<CHB, EXACT, true, SURE_B>(b, members, prep, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
         for (int p = 0; p < CHB; p++) {
-            if (EXACT || p < nB) {
+            if (EXACT || p < SURE_B || p < nB) {
                 const uint32_t key = composite_key(b[p]);
                 if (p > 0) tie_min = min(tie_min, key ^ prev);
                 if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CHB - 1 : p == nB - 1) is_nan |= key > 0xFF800000u;
+                if (EXACT ? p == CHB - 1 : (p >= SURE_B && p == nB - 1)) is_nan |= key > 0xFF800000u;
                 prev = key;
                 // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
                 discordant += CH - int32_t(lower_bound_col<CH>(&keysA[lane], key, tie_min));
             }
         }
-        discordant += chunk_inversions<CHB>(b, nB, EXACT);
+        discordant += chunk_inversions<CHB, SURE_B>(b, nB, EXACT);
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
@@ -647,7 +653,6 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     }
     if (ref.prepare()) launch_spearman_prep(ref, d_members, cs, d_prep, s);
     if (!ref.run()) return hipGetLastError();
-    const bool narrow_b = env_int("CRF_RANK_NARROW_B", 1) != 0;  // size chunk B's network to the member count (tuning: 0)
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
@@ -657,8 +662,12 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             if (d_todo && cs > 16 && (cs < 32 || env_flag("CRF_RANK_SPLIT32"))) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const unsigned blocks = unsigned((num_voxels + 63) / 64);
-                hipLaunchKernelGGL((spearman_split_kernel<16, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                   d_prep, d_out, num_voxels, cs, d_todo);
+                if (cs <= 24)
+                    hipLaunchKernelGGL((spearman_split_kernel<16, false, 4, 8>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((spearman_split_kernel<16, false, 4, 16>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       d_prep, d_out, num_voxels, cs, d_todo);
                 launch_spearman_n<32, 4>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 split = true;
                 break;
@@ -675,9 +684,11 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             if (d_todo && cs > 32 && (cs < 64 || env_split64())) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
-                if (cs <= 48 && narrow_b)  // chunk B sorted by a 16-network
+                if (cs <= 40)  // chunk B sorted by the smallest network of a multiple of 8 elements that holds it
+                    launch_spearman_split<32, 8, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 48)
                     launch_spearman_split<32, 16, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 56 && narrow_b)
+                else if (cs <= 56)
                     launch_spearman_split<32, 24, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_spearman_split<32, 32, 4>(exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
@@ -696,18 +707,23 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             // monolithic 7.5 ms / 19 ms
             if (d_todo && env_waves(2) != 0) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
-                if (cs <= 80 && narrow_b)
+                const bool wide_exact = env_exact() && getenv("CRF_RANK_EXACT");  // only on request
+                if (cs <= 72)
+                    launch_spearman_split<64, 8, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 80)
                     launch_spearman_split<64, 16, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 96 && narrow_b)
+                else if (cs <= 88)  // merge-exchange networks exist for any size
+                    launch_spearman_split<64, 24, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 96)
                     launch_spearman_split<64, 32, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 104 && narrow_b)  // merge-exchange networks exist for any size
+                else if (cs <= 104)
                     launch_spearman_split<64, 40, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 112 && narrow_b)
+                else if (cs <= 112)
                     launch_spearman_split<64, 48, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 120 && narrow_b)
-                    launch_spearman_split<64, 56, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 120)  // 56 / 64: the unguarded instantiations spill (120: 3.96 vs 3.78 ms, 128: 4.83 vs 4.10 ms)
+                    launch_spearman_split<64, 56, 2>(wide_exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else
-                    launch_spearman_split<64, 64, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
+                    launch_spearman_split<64, 64, 2>(wide_exact, d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 launch_spearman_n<128, 1>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
                 split = true;
             } else {
@@ -736,7 +752,6 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     int* prep = reinterpret_cast<int*>(d_prep);
     if (ref.prepare()) launch_kendall_prep(ref, d_members, cs, n_pad, prep, s);
     if (!ref.run()) return hipGetLastError();
-    const bool narrow_b = env_int("CRF_RANK_NARROW_B", 1) != 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
@@ -746,8 +761,12 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
             if (d_todo && cs > 16 && env_int("CRF_RANK_SPLIT32", 1) != 0) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const unsigned blocks = unsigned((num_voxels + 63) / 64);
-                hipLaunchKernelGGL((kendall_split_kernel<16, false, 4>), dim3(blocks), dim3(64), 0, s, d_members,
-                                   prep, d_out, num_voxels, cs, d_todo);
+                if (cs <= 24)
+                    hipLaunchKernelGGL((kendall_split_kernel<16, false, 4, 8, 32>), dim3(blocks), dim3(64), 0, s, d_members,
+                                       prep, d_out, num_voxels, cs, d_todo);
+                else
+                    hipLaunchKernelGGL((kendall_split_kernel<16, false, 4, 16, 32>), dim3(blocks), dim3(64), 0, s,
+                                       d_members, prep, d_out, num_voxels, cs, d_todo);
                 launch_kendall_n<32, 4>(d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 split = true;
                 break;
@@ -764,9 +783,11 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
             if (d_todo && cs > 32 && env_split64_default_on()) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
-                if (cs <= 48 && narrow_b)
+                if (cs <= 40)
+                    launch_kendall_split<32, 8, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 48)
                     launch_kendall_split<32, 16, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 56 && narrow_b)
+                else if (cs <= 56)
                     launch_kendall_split<32, 24, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_kendall_split<32, 32, 4>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
@@ -786,15 +807,19 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
                 // the guarded instantiation compiles to 226 VGPRs without scratch and is the fastest for every cs
                 // (4.8 ms at 256^3 x 128 vs 12.8 ms unguarded, 13.9-27.7 ms monolithic)
                 const bool exact = env_exact() && getenv("CRF_RANK_EXACT");
-                if (cs <= 80 && narrow_b)
+                if (cs <= 72)
+                    launch_kendall_split<64, 8, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 80)
                     launch_kendall_split<64, 16, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 96 && narrow_b)
+                else if (cs <= 88)
+                    launch_kendall_split<64, 24, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
+                else if (cs <= 96)
                     launch_kendall_split<64, 32, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 104 && narrow_b)
+                else if (cs <= 104)
                     launch_kendall_split<64, 40, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 112 && narrow_b)
+                else if (cs <= 112)
                     launch_kendall_split<64, 48, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
-                else if (cs <= 120 && narrow_b)
+                else if (cs <= 120)
                     launch_kendall_split<64, 56, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
                 else
                     launch_kendall_split<64, 64, 2>(exact, d_members, prep, d_out, num_voxels, cs, s, d_todo);
