@@ -69,7 +69,10 @@ __global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const fl
     }
 }
 
-template <int N, bool EXACT, int MIN_WAVES>
+// LC: slots loaded per batch (N = all loads first; a smaller batch bounds the live values to N codes + LC samples, which
+// keeps the wide instantiations inside the 256 registers of two waves per SIMD -- 63 loads in flight is the hardware
+// limit anyway)
+template <int N, bool EXACT, int MIN_WAVES, int LC = N>
 __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* const* __restrict__ members,
                                                                   const int* __restrict__ prep,
                                                                   const double* __restrict__ tableT,
@@ -93,19 +96,24 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     int total = 0;
     const float range_q = max_q - min_q;
     const double nbd = double(nb);
-    {
-        // all loads first, branch free: a slot past cs loads at an out-of-range offset (0, no memory request) and its
-        // code is forced to the pad code below
-        float y[N];
+    static_assert(N % LC == 0, "whole batches");
 #pragma unroll
-        for (int e = 0; e < N; e++)
-            y[e] = load_member_nt(members[is_member(e) ? e : cs - 1], bytes,
+    for (int base = 0; base < N; base += LC) {
+        // a batch of loads first, branch free: a slot past cs loads at an out-of-range offset (0, no memory request)
+        // and its code is forced to the pad code below
+        float y[LC];
+#pragma unroll
+        for (int i = 0; i < LC; i++) {
+            const int e = base + i;
+            y[i] = load_member_nt(members[is_member(e) ? e : cs - 1], bytes,
                                   is_member(e) ? byte_offset : kOutOfRangeOffset);
+        }
 #pragma unroll
-        for (int e = 0; e < N; e++) {
+        for (int i = 0; i < LC; i++) {
+            const int e = base + i;
             const bool member = is_member(e);
-            is_nan |= member && (y[e] != y[e]);
-            const float q01 = (y[e] - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
+            is_nan |= member && (y[i] != y[i]);
+            const float q01 = (y[i] - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
             const int b0 = prep[e];                      // pads: kInvalidBin (binned_prep_kernel)
             const bool valid = member && (q01 == q01) && b0 != kInvalidBin;
             int b1 = int(double(q01) * nbd);
@@ -113,6 +121,12 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
             a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
             total += valid ? 1 : 0;
         }
+        if (LC < N) __builtin_amdgcn_sched_barrier(0);  // the next batch is not hoisted above this one's conversion
+        // pin the NaN flag here: left alone the compiler sinks the y != y compares to the end of the kernel and keeps
+        // all N samples alive (in scratch from N = 96 on) across the sort
+        uint32_t nan_flag = is_nan ? 1u : 0u;
+        asm volatile("" : "+v"(nan_flag));
+        is_nan = nan_flag != 0u;
     }
     const bool slow = (total != cs) || !ref_all_valid;
     const bool any_slow = __any(slow);
@@ -122,11 +136,14 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
             if (is_member(e)) codes[e * 64 + lane] = uint16_t(a[e] & 0xFFFFu);  // pad -> 0xFFFF
     }
 
+    __builtin_amdgcn_sched_barrier(0);
     SortNet32<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
     double mi_y = -sx, joint = 0.0;
     uint32_t cell_len = 0, col_len = 0;
 #pragma unroll
     for (int p = 0; p < N; p++) {
+        if (p % 8 == 0) __builtin_amdgcn_sched_barrier(0);  // bounds the table look-ups hoisted ahead of the sums
         // guarded instantiation: the cs - total .. pads (kPadCode, the largest code) sort behind the real samples;
         // a pad position contributes T[0] = 0
         const bool member = is_member(p);
@@ -388,15 +405,15 @@ __global__ __launch_bounds__(64) void mi_binned_hist_kernel(const float* const* 
 
 namespace {
 
-template <int N, int MIN_WAVES>
+template <int N, int MIN_WAVES, int LC = N>
 void launch_binned_n(const float* const* d_members, const int* prep, const double* tableT, float* d_out,
                      size_t num_voxels, int cs, const BinnedArgs& a, hipStream_t s) {
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     if (cs == N)
-        hipLaunchKernelGGL((mi_binned_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, prep,
+        hipLaunchKernelGGL((mi_binned_kernel<N, true, MIN_WAVES, LC>), dim3(blocks), dim3(64), 0, s, d_members, prep,
                            tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
     else
-        hipLaunchKernelGGL((mi_binned_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, prep,
+        hipLaunchKernelGGL((mi_binned_kernel<N, false, MIN_WAVES, LC>), dim3(blocks), dim3(64), 0, s, d_members, prep,
                            tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
 }
 
@@ -459,19 +476,18 @@ hipError_t launch_mi_binned(const float* const* d_members, int cs, size_t num_vo
     if (ref.prepare()) launch_binned_prep(ref, d_members, cs, n_pad, a, tableT, prep, s);
     if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    // waves/SIMD per size from measurements at 256^3 (profiles/tuning_r01.md): 64 members 1.61 ms at 2 waves (2.0 ms at
-    // 4, with scratch), 128 members 5.0 ms at 1 wave (5.7 ms at 2)
-    // (the other occupancy variants were measured and dropped: 64 members 2.0 ms at 4 waves / 1.69 at 3; 112 members
-    // 5.5 ms at 1 wave; 128 members 5.7 ms at 2 waves -- profiles/tuning_r01.md)
+    // waves/SIMD per size from measurements at 256^3 (profiles/tuning_r01.md), after the NaN flag was pinned (the kernel
+    // then needs ~2 registers per member): 64 members 1.41 ms at 4 waves (1.46 at 2), 80: 1.89 ms at 3 (2.14 at 2),
+    // 128: 3.50 ms at 2 (5.16 at 1)
     switch (n_pad) {
         case 16: launch_binned_n<16, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
         case 32: launch_binned_n<32, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
         case 48: launch_binned_n<48, 3>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
-        case 64: launch_binned_n<64, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
-        case 80: launch_binned_n<80, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 64: launch_binned_n<64, 4>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        case 80: launch_binned_n<80, 3>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
         case 96: launch_binned_n<96, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
         case 112: launch_binned_n<112, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
-        default: launch_binned_n<128, 1>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
+        default: launch_binned_n<128, 2>(d_members, prep, tableT, d_out, num_voxels, cs, a, s); break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "mi_binned_kernel";
