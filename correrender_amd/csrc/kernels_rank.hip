@@ -128,6 +128,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
                                                                  float* __restrict__ out, size_t num_voxels, int cs,
                                                                  const uint32_t* __restrict__ todo) {
     __shared__ uint16_t rank2[N * 64];
+    // N = 16 serves 9..15 members only (<= 8 members: the N = 8 instantiation): its first 8 slots need no guard
+    constexpr int SURE = (N == 16) ? 8 : 0;
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const uint32_t count = todo ? todo[0] : 0u;
@@ -144,12 +146,12 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
         float y[N];
 #pragma unroll
         for (int e = 0; e < N; e++)
-            y[e] = load_member_nt(members[EXACT ? e : (e < cs ? e : cs - 1)], bytes,
-                                  (EXACT || e < cs) ? byte_offset : kOutOfRangeOffset);
+            y[e] = load_member_nt(members[(EXACT || e < SURE) ? e : (e < cs ? e : cs - 1)], bytes,
+                                  (EXACT || e < SURE || e < cs) ? byte_offset : kOutOfRangeOffset);
 #pragma unroll
         for (int e = 0; e < N; e++) {
             const float yc = y[e] + 0.0f;  // -0.0 -> +0.0 so that key equality is float equality
-            a[e] = make_composite((EXACT || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
+            a[e] = make_composite((EXACT || e < SURE || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
         is_nan |= composite_key(a[N - 1]) > 0xFF800000u;
     } else {
 #pragma unroll
-        for (int p = 0; p < N; p++) is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
+        for (int p = (SURE > 0 ? SURE : 0); p < N; p++)  // position cs - 1 holds the largest real key
+            is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
     }
 
     // (the pads form a tie run of their own behind the cs real elements: scanning them too is harmless and keeps the
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     // ranks back in member order (same lane wrote them: program order suffices, no barrier)
     float r[N];
 #pragma unroll
-    for (int e = 0; e < N; e++) r[e] = (EXACT || e < cs) ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
-    float res = pearson_tail<N, EXACT>(r, prep, cs);
+    for (int e = 0; e < N; e++) r[e] = (EXACT || e < SURE || e < cs) ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
+    float res = pearson_tail<N, EXACT, SURE>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) store_result_nt(out + v, res);
     if (todo == nullptr) break;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
                                                                 size_t num_voxels, int cs,
                                                                 const uint32_t* __restrict__ todo) {
     __shared__ uint8_t gend_lds[N];
+    constexpr int SURE = (N == 16) ? 8 : 0;  // see spearman_kernel
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const bool x_ties = prep[2 * N + 1] != 0;  // wave-uniform
@@ -230,11 +234,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
         // kOutOfRangeOffset: no memory request)
         float y[N];
 #pragma unroll
-        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[prep[e]], bytes, (EXACT || e < cs) ? byte_offset : kOutOfRangeOffset);
+        for (int e = 0; e < N; e++) y[e] = load_member_nt(members[prep[e]], bytes, (EXACT || e < SURE || e < cs) ? byte_offset : kOutOfRangeOffset);
 #pragma unroll
         for (int e = 0; e < N; e++) {
             const float yc = y[e] + 0.0f;
-            a[e] = make_composite((EXACT || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
+            a[e] = make_composite((EXACT || e < SURE || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
         is_nan |= composite_key(a[N - 1]) > 0xFF800000u;
     } else {
 #pragma unroll
-        for (int p = 0; p < N; p++) is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
+        for (int p = (SURE > 0 ? SURE : 0); p < N; p++)
+            is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
     }
 
     constexpr int W = (N + 63) / 64;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
         // ties in y: a run of t equal values contributes 0+1+...+(t-1) = t(t-1)/2
         const uint32_t key = composite_key(a[p]);
         if (p > 0) {
-            run = ((EXACT || p < cs) && key == prev_key) ? run + 1 : 0;
+            run = ((EXACT || p < SURE || p < cs) && key == prev_key) ? run + 1 : 0;
             n2 += run;
         }
         prev_key = key;
@@ -612,7 +617,7 @@ void launch_kendall_split(bool exact, const float* const* d_members, const int* 
                            d_prep, d_out, num_voxels, cs, d_todo);
 }
 
-int pad_pow2(int cs) { return cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
+int pad_pow2(int cs) { return cs <= 8 ? 8 : cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128; }
 
 int env_int(const char* name, int fallback) {
     const char* v = getenv(name);
@@ -655,6 +660,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
     if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (pad_pow2(cs)) {
+        case 8: launch_spearman_n<8, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
         case 16: launch_spearman_n<16, 4>(d_members, d_prep, d_out, num_voxels, cs, s); break;
         case 32:
             // measured at 256^3: cs = 32: monolithic unguarded 0.62-0.66 ms, split 0.65 ms; cs = 24: monolithic guarded
@@ -754,6 +760,7 @@ hipError_t launch_kendall(const float* const* d_members, int cs, size_t num_voxe
     if (!ref.run()) return hipGetLastError();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     switch (n_pad) {
+        case 8: launch_kendall_n<8, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
         case 16: launch_kendall_n<16, 4>(d_members, prep, d_out, num_voxels, cs, s); break;
         case 32:
             // measured at 256^3: cs = 32: split 0.55 ms vs monolithic 0.63-1.23 ms; cs = 24: 0.46 vs 1.0-2.4 ms;

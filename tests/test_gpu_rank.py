@@ -29,7 +29,7 @@ def _check(engine, oracle, ens, ref_xyz, measure, omeasure, what, reference_valu
 
 
 @pytest.mark.parametrize("measure,omeasure", MEASURES)
-@pytest.mark.parametrize("cs", [2, 3, 7, 16, 17, 20, 24, 32, 33, 40, 48, 50, 64, 65, 72, 96, 100, 112, 128])
+@pytest.mark.parametrize("cs", [2, 3, 7, 8, 9, 12, 15, 16, 17, 20, 24, 25, 32, 33, 40, 41, 48, 50, 57, 64, 65, 72, 73, 81, 88, 96, 100, 105, 112, 113, 121, 128])
 def test_rank_member_counts(engine, oracle, measure, omeasure, cs):
     ens = synth.box_ensemble(20, 12, 9, cs, seed=100 + cs)
     _check(engine, oracle, ens, (5, 6, 4), measure, omeasure, f"{measure.name} cs={cs}")
@@ -40,7 +40,7 @@ def test_rank_ties_everywhere(engine, oracle, measure, omeasure):
     """Heavily tied data (values rounded to a few levels): fractional ranks, tau-b tie terms, x-tie groups, the
     reference's ignored joint ties."""
     rng = np.random.default_rng(3)
-    for cs in (8, 20, 24, 48, 64, 100, 128):   # > 16: split-sort kernels + deferred (tie) list handled by the monolithic pass
+    for cs in (5, 8, 12, 20, 24, 48, 64, 72, 88, 100, 128):   # > 16: split-sort kernels + deferred (tie) list handled by the monolithic pass
         ens = np.round(rng.standard_normal((cs, 4, 8, 16)) * 1.5).astype(np.float32)
         ens[:, 0, 0, 0] = 2.0                       # all-equal voxel: 0/0 -> NaN (Kendall), NaN (Spearman)
         ens[:, 0, 0, 1] = np.arange(cs)             # strictly increasing
@@ -84,17 +84,22 @@ def test_kendall_known_answer(engine):
 
 
 @pytest.mark.parametrize("measure,omeasure", MEASURES)
-def test_rank_nan_and_inf(engine, oracle, measure, omeasure):
-    rng = np.random.default_rng(5)
-    ens = rng.standard_normal((40, 4, 8, 16)).astype(np.float32)
+@pytest.mark.parametrize("cs", [6, 8, 12, 16, 20, 40, 64, 70, 100, 128])
+def test_rank_nan_and_inf(engine, oracle, measure, omeasure, cs):
+    """NaN in the first slot, the last slot (largest key of the padded kernels) and in either chunk of the split
+    kernels; infinities are ordinary ordered values."""
+    rng = np.random.default_rng(5 + cs)
+    ens = rng.standard_normal((cs, 4, 8, 16)).astype(np.float32)
     ens[3, 1, 2, 3] = np.nan           # NaN in the query ensemble -> quiet NaN (CorrelationCalculator.cpp:929-940)
-    ens[39, 1, 2, 4] = np.nan
-    ens[0, 1, 2, 5] = np.inf           # infinities are ordinary ordered values
-    ens[7, 1, 2, 5] = np.inf
-    ens[9, 1, 2, 6] = -np.inf
-    got = _check(engine, oracle, ens, (0, 0, 0), measure, omeasure, f"{measure.name} nan/inf")
+    ens[cs - 1, 1, 2, 4] = np.nan
+    ens[0, 1, 2, 7] = np.nan
+    ens[cs // 2, 1, 2, 8] = -np.nan
+    ens[0, 1, 2, 5] = np.inf
+    ens[cs - 2, 1, 2, 5] = np.inf
+    ens[cs - 1, 1, 2, 6] = -np.inf
+    got = _check(engine, oracle, ens, (0, 0, 0), measure, omeasure, f"{measure.name} nan/inf cs={cs}")
     g = got.reshape(4, 8, 16)
-    assert np.isnan(g[1, 2, 3]) and np.isnan(g[1, 2, 4]) and np.isfinite(g[1, 2, 5])
+    assert np.isnan(g[1, 2, [3, 4, 7, 8]]).all() and np.isfinite(g[1, 2, 5]) and np.isfinite(g[1, 2, 6])
 
 
 @pytest.mark.parametrize("measure", [Measure.SPEARMAN, Measure.KENDALL])
