@@ -444,6 +444,16 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
     }
     if (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL || p->measure == CRF_MI_BINNED ||
         p->measure == CRF_BINNED_MI_CC) {
+        const char* force_direct = getenv("CRF_SYMMETRIC_DIRECT");  // tuning / tests: the any-member-count kernel
+        if (!(force_direct && *force_direct == '1')) {
+            e = crf::launch_sorted_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->measure,
+                                             p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query, c->d_tables,
+                                             out, s);
+            c->last_kernel = "sorted_symmetric_kernel";
+        }
+    }
+    if (e == hipErrorNotSupported && (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL ||
+                                      p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC)) {
         if (int r = ensure_workspace(c, crf::direct_symmetric_workspace_bytes(c->cs, c->num_voxels, p->measure))) return r;
         e = crf::launch_direct_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->measure, p->num_bins,
                                          p->min_ref, p->max_ref, p->min_query, p->max_query, c->d_tables, c->d_workspace,

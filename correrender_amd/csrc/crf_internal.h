@@ -145,6 +145,10 @@ hipError_t launch_pair_requests(const float* const* d_members_i, const float* co
                                 const double* d_tables, unsigned char* d_workspace, float* d_out, hipStream_t s);
 // symmetric field mode, Spearman (measure 1) / Kendall (2) / binned MI (3, 5), any member count (kernels_generic.hip)
 size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure);
+// sort-based symmetric kernels (kernels_symmetric.hip): 2 <= cs <= kMaxSortMembers, measures 1, 2, 3, 5
+hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                   size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
+                                   float max_y, const double* d_tables, float* d_out, hipStream_t s);
 hipError_t launch_direct_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
                                    size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
                                    float max_y, const double* d_tables, unsigned char* d_workspace, float* d_out,

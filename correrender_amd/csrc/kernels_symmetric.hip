@@ -1,0 +1,540 @@
+// kernels_symmetric.hip -- SEPARATE_SYMMETRIC field mode (CRF_FLAG_SYMMETRIC; CorrelationMain.glsl:10-15 in the reference:
+// first field vs second field AT THE SAME VOXEL) for Spearman, Kendall tau-b and binned mutual information, member
+// counts up to 128, by per-lane sorting networks.
+//
+// Both vectors of a voxel depend on the voxel, so nothing can be prepared once per evaluation: the one-reference
+// kernels' preparation (ranks / sort order / bins of the reference vector) happens per voxel here, with the same
+// register-resident networks (crf_device.h).  The any-member-count fallback (direct_symmetric_kernel,
+// kernels_generic.hip) counts in O(cs^2) per voxel; at 256^3 x 64 it needs 25 / 21 / 37 ms where these need a few.
+//   Spearman: two sorts -> doubled fractional ranks of X and of Y in two 16-bit LDS columns -> computePearson2<float>
+//             on the two rank vectors in member order (Correlation.cpp:141-174).
+//   Kendall : sort X (key, member) -> position p in the X order is the element's slot; last position of its X-tie
+//             group in an 8-bit LDS column; the Y values, parked in an LDS column by member, are picked up in slot
+//             order and sorted as (key, slot); the slot sequence's inversions beyond the X-tie group are the discordant
+//             pairs (same bitset walk as kendall_kernel); n1 / n2 from the tie runs of the two sorted sequences.
+//   Binned  : codes b1 << 8 | b0 sorted -> joint cells and Y bins as runs; the byte-swapped codes sorted again -> X bins.
+//             Voxels with skipped samples (NaN after normalisation) take the O(cs^2) path over the LDS code column.
+// One lane per voxel, one wave per block; pads (slots >= cs) load at kOutOfRangeOffset and sort last.
+#include <cstdlib>
+
+#include "crf_device.h"
+#include "crf_internal.h"
+#include "crf_mi_device.h"
+
+namespace crf {
+
+namespace {
+
+constexpr uint32_t kPadKey = 0xFFFFFFFFu;  // sorts after every real value (orderable_key(+inf) = 0xFF800000)
+
+// the first N/2 slots are members whatever cs is: launch_* picks the smallest N in {16, 32, 64, 128} that holds cs
+template <int N>
+constexpr int sure_slots() {
+    return N > 16 ? N / 2 : 0;
+}
+
+template <int N, bool EXACT>
+__device__ __forceinline__ void load_composites(composite_t (&a)[N], const float* const* __restrict__ members, int cs,
+                                                uint32_t bytes, uint32_t byte_offset) {
+    constexpr int SURE = sure_slots<N>();
+    float y[N];
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const bool real = EXACT || e < SURE || e < cs;
+        y[e] = load_member_nt(members[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
+    }
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const float yc = y[e] + 0.0f;  // -0.0 -> +0.0: key equality is float equality
+        a[e] = make_composite((EXACT || e < SURE || e < cs) ? orderable_key(yc) : kPadKey, uint32_t(e));
+    }
+}
+
+// NaNs sort to the ends (see kernels_rank.hip): smallest key below key(-inf), or largest REAL key above key(+inf)
+template <int N, bool EXACT>
+__device__ __forceinline__ bool sorted_keys_hold_nan(const composite_t (&a)[N], int cs) {
+    constexpr int SURE = sure_slots<N>();
+    bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
+    if constexpr (EXACT) {
+        is_nan |= composite_key(a[N - 1]) > 0xFF800000u;
+    } else {
+#pragma unroll
+        for (int p = (SURE > 0 ? SURE - 1 : 0); p < N; p++)
+            is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
+    }
+    return is_nan;
+}
+
+// doubled fractional ranks (2 * rank, computeRanks, Correlation.cpp:277-303) of one side into the lane's LDS column
+template <int N, bool EXACT>
+__device__ __forceinline__ bool rank_side(const float* const* __restrict__ members, int cs, uint32_t bytes,
+                                          uint32_t byte_offset, uint16_t* __restrict__ rank2) {
+    composite_t a[N];
+    load_composites<N, EXACT>(a, members, cs, bytes, byte_offset);
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool is_nan = sorted_keys_hold_nan<N, EXACT>(a, cs);
+    uint32_t run_start = 0;  // forward scan: first position of the tie run, parked in bits 8..15 of the low word
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        if (p > 0) {
+            const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
+            run_start = same ? run_start : uint32_t(p);
+        }
+        a[p] = composite_or_low(a[p], run_start << 8);
+        if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t run_end = 0;  // backward scan: last position of the run; 2 * rank = start + end + 2
+#pragma unroll
+    for (int p = N - 1; p >= 0; p--) {
+        bool same = false;
+        if (p < N - 1) same = composite_key(a[p]) == composite_key(a[p + 1]);  // real vs pad: equal only for a NaN
+        run_end = same ? run_end : uint32_t(p);
+        const uint32_t low = composite_low(a[p]);
+        rank2[(low & 0xFFu) * 64] = uint16_t(((low >> 8) & 0xFFu) + run_end + 2u);
+        if ((p & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    return is_nan;
+}
+
+}  // namespace
+
+template <int N, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void spearman_symmetric_kernel(const float* const* __restrict__ members_x,
+                                                                           const float* const* __restrict__ members_y,
+                                                                           float* __restrict__ out, size_t num_voxels,
+                                                                           int cs) {
+    __shared__ uint16_t rank2[2 * N * 64];
+    constexpr int SURE = sure_slots<N>();
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
+    bool is_nan = rank_side<N, EXACT>(members_x, cs, bytes, byte_offset, rank2 + lane);
+    uint32_t nan_flag = is_nan ? 1u : 0u;
+    uint32_t offset_y = byte_offset;
+    order_after(nan_flag, offset_y);  // the second side starts after the first is complete
+    __builtin_amdgcn_sched_barrier(0);
+    is_nan = rank_side<N, EXACT>(members_y, cs, bytes, offset_y, rank2 + N * 64 + lane);
+    is_nan |= nan_flag != 0u;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // computePearson2<float>(ranksX, ranksY, cs), sequential fp32, member order; pads contribute +0
+    float rx[N], ry[N];
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const bool member = EXACT || e < SURE || e < cs;
+        rx[e] = member ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
+        ry[e] = member ? 0.5f * float(rank2[(N + e) * 64 + lane]) : 0.0f;
+    }
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanX = 0.0f, meanY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        meanX += invN * rx[e];
+        meanY += invN * ry[e];
+    }
+    float varX = 0.0f, varY = 0.0f;
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const bool member = EXACT || e < SURE || e < cs;
+        rx[e] = member ? rx[e] - meanX : 0.0f;
+        ry[e] = member ? ry[e] - meanY : 0.0f;
+        varX += invNm1 * rx[e] * rx[e];
+        varY += invNm1 * ry[e] * ry[e];
+    }
+    const float sdX = sqrtf(varX), sdY = sqrtf(varY);
+    float r = 0.0f;
+    if (__all(exact_div_guard(meanX, sdX) && exact_div_guard(meanY, sdY))) {
+        const float rcpX = 1.0f / sdX, rcpY = 1.0f / sdY;
+#pragma unroll
+        for (int e = 0; e < N; e++) r += invNm1 * exact_div(rx[e], sdX, rcpX) * exact_div(ry[e], sdY, rcpY);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool member = EXACT || e < SURE || e < cs;
+            r += member ? invNm1 * (rx[e] / sdX) * (ry[e] / sdY) : 0.0f;
+        }
+    }
+    if (is_nan) r = __uint_as_float(0x7FC00000u);
+    if (v < num_voxels) store_result_nt(out + v, r);
+}
+
+template <int N, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const float* const* __restrict__ members_x,
+                                                                          const float* const* __restrict__ members_y,
+                                                                          float* __restrict__ out, size_t num_voxels,
+                                                                          int cs) {
+    __shared__ float ycol[N * 64];    // [member][lane]
+    __shared__ uint8_t gend[N * 64];  // [position in the X order][lane]: last position of its X-tie group
+    __shared__ uint8_t member_at[N * 64];  // [position in the X order][lane]: the member there
+    constexpr int SURE = sure_slots<N>();
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    {
+        float y[N];  // Y by member into the lane's LDS column (pads: 0, never picked up)
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool real = EXACT || e < SURE || e < cs;
+            y[e] = load_member_nt(members_y[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
+        }
+#pragma unroll
+        for (int e = 0; e < N; e++) ycol[e * 64 + lane] = y[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bool is_nan;
+    int32_t n1 = 0;
+    {
+        composite_t a[N];
+        load_composites<N, EXACT>(a, members_x, cs, bytes, byte_offset);
+        __builtin_amdgcn_sched_barrier(0);
+        SortNet<N>::sort(a);
+        __builtin_amdgcn_sched_barrier(0);
+        is_nan = sorted_keys_hold_nan<N, EXACT>(a, cs);
+        // ties in X: a run of t equal values contributes t(t-1)/2 (computeTiesB, Correlation.cpp:305-329); pads excluded
+        int32_t run = 0;
+#pragma unroll
+        for (int p = 1; p < N; p++) {
+            const bool same = composite_key(a[p]) == composite_key(a[p - 1]);
+            run = ((EXACT || p < SURE || p < cs) && same) ? run + 1 : 0;
+            n1 += run;
+        }
+        uint32_t run_end = 0;
+#pragma unroll
+        for (int p = N - 1; p >= 0; p--) {
+            bool same = false;
+            if (p < N - 1) same = composite_key(a[p]) == composite_key(a[p + 1]);
+            run_end = same ? run_end : uint32_t(p);
+            gend[p * 64 + lane] = uint8_t(run_end);
+            member_at[p * 64 + lane] = uint8_t(composite_low(a[p]) & 0xFFu);
+            if ((p & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t nan_flag = is_nan ? 1u : 0u;
+    int32_t n1_pinned = n1;
+    uint32_t lane_b = uint32_t(lane);  // the LDS reads below are addressed through a value pinned behind the X phase:
+    order_after(nan_flag, n1_pinned);  // the X composites are dead before the Y composites are built
+    order_after(n1_pinned, lane_b);
+    is_nan = nan_flag != 0u;
+    n1 = n1_pinned;
+    composite_t b[N];  // (Y key, slot) in slot order
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        const uint32_t member = uint32_t(member_at[p * 64 + lane_b]);
+        const float yc = ycol[member * 64 + lane_b] + 0.0f;
+        b[p] = make_composite((EXACT || p < SURE || p < cs) ? orderable_key(yc) : kPadKey, uint32_t(p));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet<N>::sort(b);
+    __builtin_amdgcn_sched_barrier(0);
+    is_nan |= sorted_keys_hold_nan<N, EXACT>(b, cs);
+
+    constexpr int W = (N + 63) / 64;
+    uint64_t seen[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) seen[w] = 0ull;
+    int32_t discordant = 0, n2 = 0, run = 0;
+    uint32_t prev_key = 0;
+    uint32_t group_end[8];
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        // pads sort behind the cs real elements in slot order and their X-tie group ends at N - 1: no discordant pair
+        const uint32_t key = composite_key(b[p]);
+        if (p > 0) {
+            run = ((EXACT || p < SURE || p < cs) && key == prev_key) ? run + 1 : 0;
+            n2 += run;
+        }
+        prev_key = key;
+        // the X-tie group ends are fetched 8 at a time, each batch ordered behind the bitset walk of the previous one
+        // (left alone, all N look-ups and masks are hoisted en bloc: scratch)
+        // (N = 128, one wave with AGPR overflow: the batches cost more scratch than they save -- 35 vs 41 ms at 256^3;
+        // there every fourth look-up is ordered behind the walk, as in kendall_kernel)
+        uint32_t slot = composite_low(b[p]) & 0xFFu;
+        uint32_t g;
+        if constexpr (N <= 64) {
+            if ((p & 7) == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    uint32_t sq = composite_low(b[p + q]) & 0xFFu;
+                    order_after(sq, seen[0]);
+                    group_end[q] = uint32_t(gend[sq * 64 + lane_b]);
+                }
+            }
+            g = group_end[p & 7];
+        } else {
+            if ((p & 3) == 0) order_after(slot, seen[0]);
+            g = uint32_t(gend[slot * 64 + lane_b]);
+        }
+        // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
+        if constexpr (W == 1) {
+            discordant += __popcll(seen[0] & (0xFFFFFFFFFFFFFFFEull << g));
+            seen[0] |= 1ull << slot;
+        } else {
+            const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
+            const uint64_t sbit = 1ull << (slot & 63u);
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
+                discordant += __popcll(seen[w] & mask);
+                seen[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
+            }
+        }
+        if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const int32_t n = cs;
+    const int32_t n0 = (n * (n - 1)) / 2;
+    const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
+    float res = float(numerator) / (sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2)));
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (v < num_voxels) store_result_nt(out + v, res);
+}
+
+struct SymmetricSortBinnedArgs {
+    int num_bins;  // <= 255
+    float min_x, max_x, min_y, max_y;
+    int to_cc;
+};
+
+template <int N, bool EXACT, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const float* const* __restrict__ members_x,
+                                                                         const float* const* __restrict__ members_y,
+                                                                         const double* __restrict__ tableT,
+                                                                         float* __restrict__ out, size_t num_voxels,
+                                                                         int cs, SymmetricSortBinnedArgs ba) {
+    __shared__ double T[N + 1];  // T[c] = (c/cs) ln(c/cs), T[0] = 0
+    __shared__ uint16_t codes[N * 64];
+    constexpr int SURE = sure_slots<N>();
+    const int lane = threadIdx.x;
+    for (int i = lane; i <= N; i += 64) T[i] = i <= cs ? tableT[i] : 0.0;
+    __syncthreads();
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const auto is_member = [cs](int e) { return EXACT || e < SURE || e < cs; };
+    const float range_x = ba.max_x - ba.min_x, range_y = ba.max_y - ba.min_y;
+    const double nbd = double(ba.num_bins);
+    const int nb = ba.num_bins;
+    uint32_t a[N];
+    bool is_nan = false;
+    int total = 0;
+    {
+        float x[N];
+#pragma unroll
+        for (int e = 0; e < N; e++)
+            x[e] = load_member_nt(members_x[is_member(e) ? e : cs - 1], bytes,
+                                  is_member(e) ? byte_offset : kOutOfRangeOffset);
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool member = is_member(e);
+            is_nan |= member && (x[e] != x[e]);
+            const float x01 = (x[e] - ba.min_x) / range_x;  // CorrelationCalculator.cpp:1061-1062
+            int b0 = int(double(x01) * nbd);
+            b0 = b0 < 0 ? 0 : (b0 > nb - 1 ? nb - 1 : b0);
+            a[e] = (member && x01 == x01) ? uint32_t(b0) : kPadCode;
+        }
+        uint32_t nan_flag = is_nan ? 1u : 0u;  // pinned: otherwise the samples stay alive to the end (kernels_binned.hip)
+        asm volatile("" : "+v"(nan_flag));
+        is_nan = nan_flag != 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float y[N];
+#pragma unroll
+        for (int e = 0; e < N; e++)
+            y[e] = load_member_nt(members_y[is_member(e) ? e : cs - 1], bytes,
+                                  is_member(e) ? byte_offset : kOutOfRangeOffset);
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool member = is_member(e);
+            is_nan |= member && (y[e] != y[e]);
+            const float y01 = (y[e] - ba.min_y) / range_y;
+            int b1 = int(double(y01) * nbd);
+            b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
+            const bool valid = member && (y01 == y01) && a[e] != kPadCode;
+            a[e] = valid ? (uint32_t(b1) << 8) | a[e] : kPadCode;
+            total += valid ? 1 : 0;
+        }
+        uint32_t nan_flag = is_nan ? 1u : 0u;
+        asm volatile("" : "+v"(nan_flag));
+        is_nan = nan_flag != 0u;
+    }
+    const bool slow = total != cs;
+    const bool any_slow = __any(slow);
+    if (any_slow) {
+#pragma unroll
+        for (int e = 0; e < N; e++)
+            if (is_member(e)) codes[e * 64 + lane] = uint16_t(a[e] & 0xFFFFu);  // pad -> 0xFFFF
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet32<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
+    // runs of equal codes = joint cells, runs of equal high bytes = Y bins; a pad position contributes T[0] = 0
+    double h_y = 0.0, joint = 0.0;
+    {
+        uint32_t cell_len = 0, col_len = 0;
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            const bool member = is_member(p);
+            uint32_t next = kPadCode;
+            if (p + 1 < N) next = is_member(p + 1) ? a[p + 1] : kPadCode;
+            cell_len++;
+            col_len++;
+            const bool end_cell = member && next != a[p];
+            const bool end_col = member && (next >> 8) != (a[p] >> 8);
+            joint += T[end_cell ? cell_len : 0u];
+            h_y += T[end_col ? col_len : 0u];
+            cell_len = end_cell ? 0u : cell_len;
+            col_len = end_col ? 0u : col_len;
+        }
+    }
+    // X bins: the low bytes sorted on their own (pads stay the largest code)
+#pragma unroll
+    for (int e = 0; e < N; e++) a[e] = a[e] == kPadCode ? kPadCode : (a[e] & 0xFFu);
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet32<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
+    double h_x = 0.0;
+    {
+        uint32_t len = 0;
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            const bool member = is_member(p);
+            uint32_t next = kPadCode;
+            if (p + 1 < N) next = is_member(p + 1) ? a[p + 1] : kPadCode;
+            len++;
+            const bool end = member && next != a[p];
+            h_x += T[end ? len : 0u];
+            len = end ? 0u : len;
+        }
+    }
+    double mi = joint - h_x - h_y;
+
+    if (any_slow && slow) {
+        // Samples were skipped: probabilities are c/total with total < cs.  Direct O(cs^2) evaluation over the lane's
+        // LDS column; the first occurrence of each bin / cell contributes its term (as mi_binned_kernel).
+        mi = 0.0;
+        if (total > 0) {
+            const double tot = double(total);
+            const double eps1 = 0.5 / double(cs);
+            const double eps2 = 0.5 / double(cs * cs);
+#pragma unroll 1
+            for (int i = 0; i < cs; i++) {
+                const uint32_t ci = codes[i * 64 + lane];
+                if (ci == 0xFFFFu) continue;
+                int cx = 0, cy = 0, cxy = 0;
+                bool fx = true, fy = true, fxy = true;
+#pragma unroll 1
+                for (int j = 0; j < cs; j++) {
+                    const uint32_t cj = codes[j * 64 + lane];
+                    if (cj == 0xFFFFu) continue;
+                    const bool ex = (cj & 0xFFu) == (ci & 0xFFu);
+                    const bool ey = (cj >> 8) == (ci >> 8);
+                    cx += ex;
+                    cy += ey;
+                    cxy += (ex && ey);
+                    if (j < i) {
+                        fx = fx && !ex;
+                        fy = fy && !ey;
+                        fxy = fxy && !(ex && ey);
+                    }
+                }
+                if (fx) {
+                    const double p = double(cx) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fy) {
+                    const double p = double(cy) / tot;
+                    if (p > eps1) mi -= p * log(p);
+                }
+                if (fxy) {
+                    const double p = double(cxy) / tot;
+                    if (p > eps2) mi += p * log(p);
+                }
+            }
+        }
+    }
+    float res = float(mi);
+    if (ba.to_cc) res = mi_to_cc(res);
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (cs == 1) res = 1.0f;
+    if (v < num_voxels) store_result_nt(out + v, res);
+}
+
+namespace {
+
+template <template <int, bool, int> class Launcher, int N, int WAVES, class... Args>
+void launch_exact_or_guarded(int cs, Args... args) {
+    if (cs == N)
+        Launcher<N, true, WAVES>::launch(args...);
+    else
+        Launcher<N, false, WAVES>::launch(args...);
+}
+
+template <int N, bool EXACT, int WAVES>
+struct SpearmanLauncher {
+    static void launch(const float* const* mx, const float* const* my, float* out, size_t num_voxels, int cs,
+                       hipStream_t s) {
+        hipLaunchKernelGGL((spearman_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64),
+                           0, s, mx, my, out, num_voxels, cs);
+    }
+};
+template <int N, bool EXACT, int WAVES>
+struct KendallLauncher {
+    static void launch(const float* const* mx, const float* const* my, float* out, size_t num_voxels, int cs,
+                       hipStream_t s) {
+        hipLaunchKernelGGL((kendall_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64),
+                           0, s, mx, my, out, num_voxels, cs);
+    }
+};
+template <int N, bool EXACT, int WAVES>
+struct BinnedLauncher {
+    static void launch(const float* const* mx, const float* const* my, const double* tableT, float* out,
+                       size_t num_voxels, int cs, SymmetricSortBinnedArgs ba, hipStream_t s) {
+        hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64), 0,
+                           s, mx, my, tableT, out, num_voxels, cs, ba);
+    }
+};
+
+}  // namespace
+
+// cs in [2, 128]; measure 1 Spearman, 2 Kendall, 3 / 5 binned MI / its correlation coefficient; hipErrorNotSupported
+// otherwise (the caller then uses direct_symmetric_kernel)
+hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                   size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
+                                   float max_y, const double* d_tables, float* d_out, hipStream_t s) {
+    if (cs < 2 || cs > kMaxSortMembers) return hipErrorNotSupported;
+    const int n = cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128;
+    if (measure == 1) {
+        switch (n) {
+            case 16: launch_exact_or_guarded<SpearmanLauncher, 16, 4>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            case 32: launch_exact_or_guarded<SpearmanLauncher, 32, 3>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            case 64: launch_exact_or_guarded<SpearmanLauncher, 64, 2>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            default: launch_exact_or_guarded<SpearmanLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+        }
+    } else if (measure == 2) {
+        switch (n) {
+            case 16: launch_exact_or_guarded<KendallLauncher, 16, 4>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            case 32: launch_exact_or_guarded<KendallLauncher, 32, 3>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            case 64: launch_exact_or_guarded<KendallLauncher, 64, 2>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            default: launch_exact_or_guarded<KendallLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+        }
+    } else if (measure == 3 || measure == 5) {
+        if (num_bins < 1 || num_bins > 255) return hipErrorNotSupported;
+        const SymmetricSortBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
+        const double* tableT = d_tables + (cs + 1);
+        switch (n) {
+            case 16: launch_exact_or_guarded<BinnedLauncher, 16, 4>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
+            case 32: launch_exact_or_guarded<BinnedLauncher, 32, 3>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
+            case 64: launch_exact_or_guarded<BinnedLauncher, 64, 3>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
+            default: launch_exact_or_guarded<BinnedLauncher, 128, 2>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
+        }
+    } else {
+        return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace crf

@@ -38,7 +38,7 @@ def _setup(engine, a, b):
 
 
 @pytest.mark.parametrize("measure,omeasure", EXACT)
-@pytest.mark.parametrize("cs", [2, 7, 16, 24, 40, 64, 100, 128, 150])
+@pytest.mark.parametrize("cs", [2, 7, 16, 17, 24, 32, 33, 40, 50, 64, 65, 100, 127, 128, 150])
 def test_symmetric_exact_measures(engine, oracle, measure, omeasure, cs):
     a, b = _two_fields(cs, seed=cs)
     a[1, 2, 3, 4] = np.nan                          # NaN on the reference side
@@ -49,6 +49,8 @@ def test_symmetric_exact_measures(engine, oracle, measure, omeasure, cs):
     got = engine.compute(measure, symmetric=True)
     want = oracle.symmetric_field(omeasure, a, b)
     assert_bit_exact(got, want, f"symmetric {measure.name} cs={cs}")
+    if measure != Measure.PEARSON:      # sort-based kernels up to 128 members, the counting kernel beyond
+        assert engine.last_kernel_name() == ("sorted_symmetric_kernel" if cs <= 128 else "direct_symmetric_kernel")
     g = got.reshape(a.shape[1:])
     assert np.isnan(g[2, 3, 4]) and np.isnan(g[3, 1, 2])
     if measure == Measure.PEARSON and cs >= 7:
@@ -66,6 +68,53 @@ def test_symmetric_mutual_information(engine, oracle, measure, omeasure, cs):
     got = engine.compute(measure, symmetric=True, k=3, num_bins=20)
     want = oracle.symmetric_field(omeasure, a, b, k=3, num_bins=20, minmax_ref=mm_a, minmax_query=mm_b)
     assert_close(got, want, f"symmetric {measure.name} cs={cs}")
+    assert bit_identical(got, want).mean() > 0.99
+
+
+@pytest.mark.parametrize("measure,omeasure", EXACT[1:])
+@pytest.mark.parametrize("cs", [12, 30, 64, 90])
+def test_symmetric_rank_measures_with_heavy_ties(engine, oracle, measure, omeasure, cs):
+    """Both fields rounded to a few levels: tie groups in X and in Y, joint ties (ignored by the reference's tau-b),
+    +0 / -0, identical and constant vectors."""
+    rng = np.random.default_rng(40 + cs)
+    a = np.round(rng.standard_normal((cs, 3, 8, 16)) * 1.5).astype(np.float32)
+    b = np.round(0.5 * a + rng.standard_normal((cs, 3, 8, 16))).astype(np.float32)
+    b[:, 0, 0, 0] = a[:, 0, 0, 0]
+    a[:, 0, 0, 1] = 1.0                                                 # constant X: division by zero as the reference
+    b[:, 0, 0, 2] = np.where(np.arange(cs) % 2 == 0, 0.0, -0.0)         # +0 / -0 are equal
+    a[:, 0, 0, 3] = np.arange(cs)
+    b[:, 0, 0, 3] = -np.arange(cs)
+    a[cs - 1, 0, 1, 0] = np.nan
+    b[0, 0, 1, 1] = -np.nan
+    a[0, 0, 1, 2] = np.inf
+    b[cs - 1, 0, 1, 2] = -np.inf
+    _setup(engine, a, b)
+    got = engine.compute(measure, symmetric=True)
+    assert_bit_exact(got, oracle.symmetric_field(omeasure, a, b), f"symmetric {measure.name} ties cs={cs}")
+    assert engine.last_kernel_name() == "sorted_symmetric_kernel"
+
+
+@pytest.mark.parametrize("cs", [10, 31, 64, 77, 128])
+@pytest.mark.parametrize("num_bins", [8, 80, 255])
+def test_symmetric_binned_sorted_kernel(engine, oracle, cs, num_bins):
+    """The sort-based binned kernel: several bin counts, infinities (samples skipped after normalisation: the
+    per-voxel O(cs^2) path) and a NaN voxel."""
+    a, b = _two_fields(cs, shape=(2, 8, 16), seed=300 + cs)
+    b[3, 1, 2, 3] = np.inf                          # max_y = inf: every finite sample normalises to 0, inf/inf is skipped
+    a[1, 1, 4, 5] = np.nan
+    _setup(engine, a, b)
+    mm_a, mm_b = oracle.minmax(a), oracle.minmax(b)
+    got = engine.compute(Measure.MUTUAL_INFORMATION_BINNED, symmetric=True, num_bins=num_bins)
+    assert engine.last_kernel_name() == "sorted_symmetric_kernel"
+    want = oracle.symmetric_field(3, a, b, num_bins=num_bins, minmax_ref=mm_a, minmax_query=mm_b)
+    assert_close(got, want, f"symmetric binned cs={cs} bins={num_bins}")
+    assert np.isnan(got.reshape(2, 8, 16)[1, 4, 5])
+    b[3, 1, 2, 3] = 0.25
+    engine.upload_secondary_members(b)
+    mm_b = oracle.minmax(b)
+    got = engine.compute(Measure.MUTUAL_INFORMATION_BINNED, symmetric=True, num_bins=num_bins)
+    want = oracle.symmetric_field(3, a, b, num_bins=num_bins, minmax_ref=mm_a, minmax_query=mm_b)
+    assert_close(got, want, f"symmetric binned (finite) cs={cs} bins={num_bins}")
     assert bit_identical(got, want).mean() > 0.99
 
 
