@@ -159,6 +159,27 @@ struct SortNet<64> {
     }
 };
 template <>
+struct SortNet<80> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[80]) {
+#define CRF_SORTNET_N 80
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet<96> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[96]) {
+#define CRF_SORTNET_N 96
+#include "sortnet.inc"
+    }
+};
+template <>
+struct SortNet<112> {
+    static __device__ __forceinline__ void sort(composite_t (&a)[112]) {
+#define CRF_SORTNET_N 112
+#include "sortnet.inc"
+    }
+};
+template <>
 struct SortNet<128> {
     static __device__ __forceinline__ void sort(composite_t (&a)[128]) {
 #define CRF_SORTNET_N 128

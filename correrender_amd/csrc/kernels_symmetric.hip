@@ -27,10 +27,10 @@ namespace {
 
 constexpr uint32_t kPadKey = 0xFFFFFFFFu;  // sorts after every real value (orderable_key(+inf) = 0xFF800000)
 
-// the first N/2 slots are members whatever cs is: launch_* picks the smallest N in {16, 32, 64, 128} that holds cs
+// the first N - 16 slots are members whatever cs is: launch_* picks the smallest N (a multiple of 16) that holds cs
 template <int N>
 constexpr int sure_slots() {
-    return N > 16 ? N / 2 : 0;
+    return N - 16;
 }
 
 template <int N, bool EXACT>
@@ -506,19 +506,29 @@ hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float*
                                    size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
                                    float max_y, const double* d_tables, float* d_out, hipStream_t s) {
     if (cs < 2 || cs > kMaxSortMembers) return hipErrorNotSupported;
-    const int n = cs <= 16 ? 16 : cs <= 32 ? 32 : cs <= 64 ? 64 : 128;
+    const int n = (cs + 15) / 16 * 16;
+#define CRF_SYM_CASE(L, N, W, ...) \
+    case N: launch_exact_or_guarded<L, N, W>(cs, __VA_ARGS__); break
     if (measure == 1) {
         switch (n) {
-            case 16: launch_exact_or_guarded<SpearmanLauncher, 16, 4>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-            case 32: launch_exact_or_guarded<SpearmanLauncher, 32, 3>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-            case 64: launch_exact_or_guarded<SpearmanLauncher, 64, 2>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            CRF_SYM_CASE(SpearmanLauncher, 16, 4, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 32, 3, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 48, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 64, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 80, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 96, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(SpearmanLauncher, 112, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
             default: launch_exact_or_guarded<SpearmanLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
         }
     } else if (measure == 2) {
         switch (n) {
-            case 16: launch_exact_or_guarded<KendallLauncher, 16, 4>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-            case 32: launch_exact_or_guarded<KendallLauncher, 32, 3>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-            case 64: launch_exact_or_guarded<KendallLauncher, 64, 2>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
+            CRF_SYM_CASE(KendallLauncher, 16, 4, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 32, 3, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 48, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 64, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 80, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 96, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
+            CRF_SYM_CASE(KendallLauncher, 112, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
             default: launch_exact_or_guarded<KendallLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
         }
     } else if (measure == 3 || measure == 5) {
@@ -526,14 +536,19 @@ hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float*
         const SymmetricSortBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
         const double* tableT = d_tables + (cs + 1);
         switch (n) {
-            case 16: launch_exact_or_guarded<BinnedLauncher, 16, 4>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
-            case 32: launch_exact_or_guarded<BinnedLauncher, 32, 3>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
-            case 64: launch_exact_or_guarded<BinnedLauncher, 64, 3>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
+            CRF_SYM_CASE(BinnedLauncher, 16, 4, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 32, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 48, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 64, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 80, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 96, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
+            CRF_SYM_CASE(BinnedLauncher, 112, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
             default: launch_exact_or_guarded<BinnedLauncher, 128, 2>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
         }
     } else {
         return hipErrorNotSupported;
     }
+#undef CRF_SYM_CASE
     return hipGetLastError();
 }
 

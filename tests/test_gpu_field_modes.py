@@ -38,7 +38,7 @@ def _setup(engine, a, b):
 
 
 @pytest.mark.parametrize("measure,omeasure", EXACT)
-@pytest.mark.parametrize("cs", [2, 7, 16, 17, 24, 32, 33, 40, 50, 64, 65, 100, 127, 128, 150])
+@pytest.mark.parametrize("cs", [2, 7, 16, 17, 24, 32, 33, 40, 48, 50, 64, 65, 80, 81, 96, 100, 112, 113, 127, 128, 150])
 def test_symmetric_exact_measures(engine, oracle, measure, omeasure, cs):
     a, b = _two_fields(cs, seed=cs)
     a[1, 2, 3, 4] = np.nan                          # NaN on the reference side
@@ -94,7 +94,7 @@ def test_symmetric_rank_measures_with_heavy_ties(engine, oracle, measure, omeasu
     assert engine.last_kernel_name() == "sorted_symmetric_kernel"
 
 
-@pytest.mark.parametrize("cs", [10, 31, 64, 77, 128])
+@pytest.mark.parametrize("cs", [10, 31, 48, 64, 77, 96, 100, 128])
 @pytest.mark.parametrize("num_bins", [8, 80, 255])
 def test_symmetric_binned_sorted_kernel(engine, oracle, cs, num_bins):
     """The sort-based binned kernel: several bin counts, infinities (samples skipped after normalisation: the
