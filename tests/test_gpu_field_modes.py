@@ -167,3 +167,23 @@ def test_two_field_modes_need_secondary_members(engine):
         engine.compute(Measure.PEARSON, symmetric=True)
     with pytest.raises(CorrFieldError, match="secondary"):
         engine.compute(Measure.PEARSON, (0, 0, 0), reference_from_secondary=True)
+
+
+@pytest.mark.parametrize("cs", [12, 24, 50, 72, 100, 128])
+def test_symmetric_kernels_agree_with_one_reference_kernels(engine, cs):
+    """Two independent kernel families, 131 072 voxels per member count: symmetric mode with a spatially constant first
+    field (= the reference vector) against the one-reference kernels with that vector (tie-heavy and tie-free data)."""
+    rng = np.random.default_rng(900 + cs)
+    vol = rng.standard_normal((cs, 32, 64, 64)).astype(np.float32)
+    vol[:, :4] = np.round(vol[:, :4] * 2)                      # slices with many ties: the deferred-voxel passes
+    for ref_values in (rng.standard_normal(cs).astype(np.float32), np.round(rng.standard_normal(cs) * 2).astype(np.float32)):
+        engine.set_grid(64, 64, 32, cs)
+        engine.upload_members(vol)
+        expect = {m: engine.compute(m, reference_values=ref_values) for m in (Measure.SPEARMAN, Measure.KENDALL)}
+        const = np.broadcast_to(ref_values[:, None, None, None], vol.shape)
+        engine.upload_members(np.ascontiguousarray(const))
+        engine.upload_secondary_members(vol)
+        for m in (Measure.SPEARMAN, Measure.KENDALL):
+            got = engine.compute(m, symmetric=True)
+            assert engine.last_kernel_name() == "sorted_symmetric_kernel"
+            assert bit_identical(got, expect[m]).all(), f"{m.name} cs={cs}: symmetric and one-reference kernels differ"

@@ -195,3 +195,40 @@ def test_ragged_million_voxels_with_many_tied_voxels(engine, oracle):
                  oracle.field(oracle_lib.MI_BINNED, ens, ref_values, num_bins=80, minmax_ref=mm), "binned ragged 1M")
     assert_close(engine.compute(Measure.MUTUAL_INFORMATION_KRASKOV, ref_xyz, k=3),
                  oracle.field(oracle_lib.MI_KRASKOV, ens, ref_values, k=3), "kraskov ragged 1M")
+
+
+def test_full_size_symmetric_kernels_agree_with_one_reference_kernels(engine, volume):
+    """Cross-check of two independent kernel families on all 16.7 M voxels: the symmetric (two-field) kernels with a
+    first field whose members are spatially constant (= the reference vector) must return exactly what the
+    one-reference kernels return for that vector -- the same estimator, computed by the split-sort / prepared kernels on
+    one side and by the per-voxel two-sort kernels on the other."""
+    engine.set_grid(XS, YS, ZS, CS)
+    engine.bind_members(volume)
+    ref_xyz = (XS // 8 + 3, YS // 8 + 1, ZS // 2)
+    ref_values = engine.gather_reference(*ref_xyz)
+    mm = engine.member_minmax()
+    expect = {}
+    out = torch.empty(XS * YS * ZS, dtype=torch.float32, device="cuda")
+    for m in (Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED):
+        kw = dict(num_bins=80, minmax_ref=mm, minmax_query=mm) if m == Measure.MUTUAL_INFORMATION_BINNED else {}
+        engine.compute_device(m, out, ref_xyz, **kw)
+        torch.cuda.synchronize()
+        expect[m] = out.clone()
+    constant = torch.empty((CS, ZS, YS, XS), dtype=torch.float32, device="cuda")
+    for c in range(CS):
+        constant[c].fill_(float(ref_values[c]))
+    engine.bind_members(constant)                  # X side = first field
+    engine.bind_secondary_members(volume)          # Y side = second field
+    for m in (Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED):
+        kw = dict(num_bins=80, minmax_ref=mm, minmax_query=mm) if m == Measure.MUTUAL_INFORMATION_BINNED else {}
+        engine.compute_device(m, out, symmetric=True, **kw)
+        torch.cuda.synchronize()
+        assert engine.last_kernel_name() == "sorted_symmetric_kernel"
+        same = (out.view(torch.int32) == expect[m].view(torch.int32)) | (torch.isnan(out) & torch.isnan(expect[m]))
+        if m == Measure.MUTUAL_INFORMATION_BINNED:   # fp64 sums in a different order: tolerance, nearly all identical
+            assert same.float().mean().item() > 0.999
+            torch.testing.assert_close(out, expect[m], rtol=1e-5, atol=1e-6, equal_nan=True)
+        else:
+            assert bool(same.all()), f"{m.name}: {int((~same).sum())} of {same.numel()} voxels differ"
+    del constant
+    torch.cuda.empty_cache()
