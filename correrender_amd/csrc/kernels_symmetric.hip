@@ -8,10 +8,10 @@
 // kernels_generic.hip) counts in O(cs^2) per voxel; at 256^3 x 64 it needs 25 / 21 / 37 ms where these need a few.
 //   Spearman: two sorts -> doubled fractional ranks of X and of Y in two 16-bit LDS columns -> computePearson2<float>
 //             on the two rank vectors in member order (Correlation.cpp:141-174).
-//   Kendall : sort X (key, member) -> position p in the X order is the element's slot; last position of its X-tie
-//             group in an 8-bit LDS column; the Y values, parked in an LDS column by member, are picked up in slot
-//             order and sorted as (key, slot); the slot sequence's inversions beyond the X-tie group are the discordant
-//             pairs (same bitset walk as kendall_kernel); n1 / n2 from the tie runs of the two sorted sequences.
+//   Kendall : sort X as (key, member) -> each member's position in the X order and the last position of its X-tie group
+//             in one 16-bit LDS column; sort Y as (key, member); walk in ascending Y with a bitset of seen X positions:
+//             positions beyond the visited element's X-tie group are its discordant pairs (elements of the current Y-tie
+//             run wait in a second bitset until the run ends); n1 / n2 from the tie runs of the two sorted sequences.
 //   Binned  : (kernels_symmetric_binned.hip) codes b1 << 8 | b0 sorted -> joint cells and Y bins as runs; the byte-swapped codes sorted again -> X bins.
 //             Voxels with skipped samples (NaN after normalisation) take the O(cs^2) path over the LDS code column.
 // One lane per voxel, one wave per block; pads (slots >= cs) load at kOutOfRangeOffset and sort last.
@@ -166,24 +166,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
                                                                           const float* const* __restrict__ members_y,
                                                                           float* __restrict__ out, size_t num_voxels,
                                                                           int cs) {
-    __shared__ float ycol[N * 64];    // [member][lane]
-    __shared__ uint8_t gend[N * 64];  // [position in the X order][lane]: last position of its X-tie group
-    __shared__ uint8_t member_at[N * 64];  // [position in the X order][lane]: the member there
+    __shared__ uint16_t xinfo[N * 64];  // [member][lane]: position in the X order | last position of its X-tie group << 8
     constexpr int SURE = sure_slots<N>();
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
-    {
-        float y[N];  // Y by member into the lane's LDS column (pads: 0, never picked up)
-#pragma unroll
-        for (int e = 0; e < N; e++) {
-            const bool real = EXACT || e < SURE || e < cs;
-            y[e] = load_member_nt(members_y[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
-        }
-#pragma unroll
-        for (int e = 0; e < N; e++) ycol[e * 64 + lane] = y[e];
-    }
-    __builtin_amdgcn_sched_barrier(0);
     bool is_nan;
     int32_t n1 = 0;
     {
@@ -207,79 +194,78 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
             bool same = false;
             if (p < N - 1) same = composite_key(a[p]) == composite_key(a[p + 1]);
             run_end = same ? run_end : uint32_t(p);
-            gend[p * 64 + lane] = uint8_t(run_end);
-            member_at[p * 64 + lane] = uint8_t(composite_low(a[p]) & 0xFFu);
+            xinfo[(composite_low(a[p]) & 0xFFu) * 64 + lane] = uint16_t(uint32_t(p) | (run_end << 8));
             if ((p & 3) == 0) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     uint32_t nan_flag = is_nan ? 1u : 0u;
+    uint32_t offset_y = byte_offset;
+    order_after(nan_flag, offset_y);  // the Y side starts after the X composites are dead
     int32_t n1_pinned = n1;
-    uint32_t lane_b = uint32_t(lane);  // the LDS reads below are addressed through a value pinned behind the X phase:
-    order_after(nan_flag, n1_pinned);  // the X composites are dead before the Y composites are built
+    uint32_t lane_b = uint32_t(lane);
     order_after(n1_pinned, lane_b);
     is_nan = nan_flag != 0u;
     n1 = n1_pinned;
-    composite_t b[N];  // (Y key, slot) in slot order
-#pragma unroll
-    for (int p = 0; p < N; p++) {
-        const uint32_t member = uint32_t(member_at[p * 64 + lane_b]);
-        const float yc = ycol[member * 64 + lane_b] + 0.0f;
-        b[p] = make_composite((EXACT || p < SURE || p < cs) ? orderable_key(yc) : kPadKey, uint32_t(p));
-    }
+    composite_t b[N];  // (Y key, member)
+    load_composites<N, EXACT>(b, members_y, cs, bytes, offset_y);
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(b);
     __builtin_amdgcn_sched_barrier(0);
     is_nan |= sorted_keys_hold_nan<N, EXACT>(b, cs);
 
+    // Walk in ascending Y.  A visited element is discordant with every element of strictly smaller Y whose X position
+    // lies beyond its own X-tie group; elements of the current Y-tie run must not count, so they wait in `pending` and
+    // join `seen` when the run ends (the one-reference kernels order equal Y by X position instead, which needs the Y
+    // values permuted into X order first).  Pads sort last on both sides and their X-tie group ends at N - 1.
     constexpr int W = (N + 63) / 64;
-    uint64_t seen[W];
+    uint64_t seen[W], pending[W];
 #pragma unroll
-    for (int w = 0; w < W; w++) seen[w] = 0ull;
+    for (int w = 0; w < W; w++) seen[w] = pending[w] = 0ull;
     int32_t discordant = 0, n2 = 0, run = 0;
     uint32_t prev_key = 0;
-    uint32_t group_end[8];
+    uint32_t info[8];
 #pragma unroll
     for (int p = 0; p < N; p++) {
-        // pads sort behind the cs real elements in slot order and their X-tie group ends at N - 1: no discordant pair
         const uint32_t key = composite_key(b[p]);
+        const bool same = p > 0 && key == prev_key;
         if (p > 0) {
-            run = ((EXACT || p < SURE || p < cs) && key == prev_key) ? run + 1 : 0;
+            run = ((EXACT || p < SURE || p < cs) && same) ? run + 1 : 0;  // ties in Y: t(t-1)/2 per run
             n2 += run;
         }
         prev_key = key;
-        // the X-tie group ends are fetched 8 at a time, each batch ordered behind the bitset walk of the previous one
-        // (left alone, all N look-ups and masks are hoisted en bloc: scratch)
-        // (N = 128, one wave with AGPR overflow: the batches cost more scratch than they save -- 35 vs 41 ms at 256^3;
-        // there every fourth look-up is ordered behind the walk, as in kendall_kernel)
-        uint32_t slot = composite_low(b[p]) & 0xFFu;
-        uint32_t g;
+        // the X-order look-ups are fetched 8 at a time, each batch ordered behind the walk of the previous one (left
+        // alone, all N look-ups and masks are hoisted en bloc: scratch); N > 64 (one wave, AGPR overflow): every fourth
         if constexpr (N <= 64) {
             if ((p & 7) == 0) {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    uint32_t sq = composite_low(b[p + q]) & 0xFFu;
-                    order_after(sq, seen[0]);
-                    group_end[q] = uint32_t(gend[sq * 64 + lane_b]);
+                    uint32_t mq = composite_low(b[p + q]) & 0xFFu;
+                    order_after(mq, seen[0]);
+                    info[q] = uint32_t(xinfo[mq * 64 + lane_b]);
                 }
             }
-            g = group_end[p & 7];
         } else {
-            if ((p & 3) == 0) order_after(slot, seen[0]);
-            g = uint32_t(gend[slot * 64 + lane_b]);
+            uint32_t mq = composite_low(b[p]) & 0xFFu;
+            if ((p & 3) == 0) order_after(mq, seen[0]);
+            info[p & 7] = uint32_t(xinfo[mq * 64 + lane_b]);
         }
-        // already-seen slots (smaller y, or equal y and smaller slot) with strictly larger x: slot' > g
+        const uint32_t slot = info[p & 7] & 0xFFu, g = info[p & 7] >> 8;
         if constexpr (W == 1) {
+            seen[0] |= same ? 0ull : pending[0];
+            pending[0] = same ? pending[0] : 0ull;
             discordant += __popcll(seen[0] & (0xFFFFFFFFFFFFFFFEull << g));
-            seen[0] |= 1ull << slot;
+            pending[0] |= 1ull << slot;
         } else {
             const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
             const uint64_t sbit = 1ull << (slot & 63u);
 #pragma unroll
             for (int w = 0; w < W; w++) {
+                seen[w] |= same ? 0ull : pending[w];
+                pending[w] = same ? pending[w] : 0ull;
                 const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
                 discordant += __popcll(seen[w] & mask);
-                seen[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
+                pending[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
             }
         }
         if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);

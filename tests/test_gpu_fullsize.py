@@ -217,6 +217,7 @@ def test_full_size_symmetric_kernels_agree_with_one_reference_kernels(engine, vo
     constant = torch.empty((CS, ZS, YS, XS), dtype=torch.float32, device="cuda")
     for c in range(CS):
         constant[c].fill_(float(ref_values[c]))
+    torch.cuda.synchronize()                       # the engine computes on its own stream
     engine.bind_members(constant)                  # X side = first field
     engine.bind_secondary_members(volume)          # Y side = second field
     for m in (Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED):
