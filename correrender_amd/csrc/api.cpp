@@ -771,10 +771,21 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, num_requests))) return r;
     const crf::PairArgs a{p->measure, p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) ? 1 : 0, 0, 0.f, 0.f, 0.f, 0.f};
-    hipError_t e = crf::launch_pair_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
-                                             static_cast<const uint32_t*>(device_requests), num_requests, a,
-                                             c->d_tables, c->d_workspace, static_cast<float*>(device_out), s);
-    c->last_kernel = "pair_request_kernel";
+    // Spearman / Kendall up to 128 members: the sort-based two-vector kernels (kernels_symmetric.hip) in request mode
+    hipError_t e = hipErrorNotSupported;
+    const char* force_generic = getenv("CRF_REQUESTS_GENERIC");  // tuning / tests: the counting kernel
+    if (!(force_generic && *force_generic == '1')) {
+        e = crf::launch_sorted_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                        static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
+                                        a.use_abs, static_cast<float*>(device_out), s);
+        c->last_kernel = "sorted_request_kernel";
+    }
+    if (e == hipErrorNotSupported) {
+        e = crf::launch_pair_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                      static_cast<const uint32_t*>(device_requests), num_requests, a, c->d_tables,
+                                      c->d_workspace, static_cast<float*>(device_out), s);
+        c->last_kernel = "pair_request_kernel";
+    }
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
     return CRF_OK;
 }

@@ -32,7 +32,8 @@ constexpr int sure_slots() {
     return N - 16;
 }
 
-template <int N, bool EXACT>
+// CACHED: default cache policy instead of non-temporal loads (pair requests revisit voxels)
+template <int N, bool EXACT, bool CACHED = false>
 __device__ __forceinline__ void load_composites(composite_t (&a)[N], const float* const* __restrict__ members, int cs,
                                                 uint32_t bytes, uint32_t byte_offset) {
     constexpr int SURE = sure_slots<N>();
@@ -40,7 +41,9 @@ __device__ __forceinline__ void load_composites(composite_t (&a)[N], const float
 #pragma unroll
     for (int e = 0; e < N; e++) {
         const bool real = EXACT || e < SURE || e < cs;
-        y[e] = load_member_nt(members[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
+        const uint32_t off = real ? byte_offset : kOutOfRangeOffset;
+        y[e] = CACHED ? load_member_cached(members[real ? e : cs - 1], bytes, off)
+                      : load_member_nt(members[real ? e : cs - 1], bytes, off);
     }
 #pragma unroll
     for (int e = 0; e < N; e++) {
@@ -65,11 +68,11 @@ __device__ __forceinline__ bool sorted_keys_hold_nan(const composite_t (&a)[N], 
 }
 
 // doubled fractional ranks (2 * rank, computeRanks, Correlation.cpp:277-303) of one side into the lane's LDS column
-template <int N, bool EXACT>
+template <int N, bool EXACT, bool CACHED = false>
 __device__ __forceinline__ bool rank_side(const float* const* __restrict__ members, int cs, uint32_t bytes,
                                           uint32_t byte_offset, uint16_t* __restrict__ rank2) {
     composite_t a[N];
-    load_composites<N, EXACT>(a, members, cs, bytes, byte_offset);
+    load_composites<N, EXACT, CACHED>(a, members, cs, bytes, byte_offset);
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
@@ -97,24 +100,47 @@ __device__ __forceinline__ bool rank_side(const float* const* __restrict__ membe
     return is_nan;
 }
 
+// What a lane works on.  Field mode (REQ = false): voxel `item` of both fields.  Request mode: pair request `item`
+// (layout {xi, yi, zi, i, xj, yj, zj, j}, HEBChart.hpp:166-168): X = the members at voxel i, Y = the members at voxel j.
+struct RequestArgs {
+    const uint32_t* requests;
+    int xs, ys;
+    int use_abs;
+};
+template <bool REQ>
+__device__ __forceinline__ void lane_offsets(const RequestArgs& ra, size_t item, size_t num_items, uint32_t& offset_x,
+                                             uint32_t& offset_y) {
+    if constexpr (REQ) {
+        offset_x = offset_y = kOutOfRangeOffset;  // lanes past the end read 0 and store nothing
+        if (item < num_items) {
+            const uint32_t* q = ra.requests + item * 8;
+            offset_x = ((q[2] * uint32_t(ra.ys) + q[1]) * uint32_t(ra.xs) + q[0]) * 4u;  // IDXS
+            offset_y = ((q[6] * uint32_t(ra.ys) + q[5]) * uint32_t(ra.xs) + q[4]) * 4u;
+        }
+    } else {
+        offset_x = offset_y = uint32_t(item) * 4u;
+    }
+}
+
 }  // namespace
 
-template <int N, bool EXACT, int MIN_WAVES>
+template <int N, bool EXACT, int MIN_WAVES, bool REQ = false>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_symmetric_kernel(const float* const* __restrict__ members_x,
                                                                            const float* const* __restrict__ members_y,
                                                                            float* __restrict__ out, size_t num_voxels,
-                                                                           int cs) {
+                                                                           int cs, size_t num_items, RequestArgs ra) {
     __shared__ uint16_t rank2[2 * N * 64];
     constexpr int SURE = sure_slots<N>();
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
-    bool is_nan = rank_side<N, EXACT>(members_x, cs, bytes, byte_offset, rank2 + lane);
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;  // lanes past the end read 0
+    uint32_t byte_offset, offset_y;
+    lane_offsets<REQ>(ra, v, num_items, byte_offset, offset_y);
+    bool is_nan = rank_side<N, EXACT, REQ>(members_x, cs, bytes, byte_offset, rank2 + lane);
     uint32_t nan_flag = is_nan ? 1u : 0u;
-    uint32_t offset_y = byte_offset;
     order_after(nan_flag, offset_y);  // the second side starts after the first is complete
     __builtin_amdgcn_sched_barrier(0);
-    is_nan = rank_side<N, EXACT>(members_y, cs, bytes, offset_y, rank2 + N * 64 + lane);
+    is_nan = rank_side<N, EXACT, REQ>(members_y, cs, bytes, offset_y, rank2 + N * 64 + lane);
     is_nan |= nan_flag != 0u;
     __builtin_amdgcn_sched_barrier(0);
 
@@ -157,25 +183,28 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_symmetric_kernel(const
             r += member ? invNm1 * (rx[e] / sdX) * (ry[e] / sdY) : 0.0f;
         }
     }
+    if (REQ && ra.use_abs) r = fabsf(r);
     if (is_nan) r = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) store_result_nt(out + v, r);
+    if (v < num_items) store_result_nt(out + v, r);
 }
 
-template <int N, bool EXACT, int MIN_WAVES>
+template <int N, bool EXACT, int MIN_WAVES, bool REQ = false>
 __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const float* const* __restrict__ members_x,
                                                                           const float* const* __restrict__ members_y,
                                                                           float* __restrict__ out, size_t num_voxels,
-                                                                          int cs) {
+                                                                          int cs, size_t num_items, RequestArgs ra) {
     __shared__ uint16_t xinfo[N * 64];  // [member][lane]: position in the X order | last position of its X-tie group << 8
     constexpr int SURE = sure_slots<N>();
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    uint32_t byte_offset, offset_y;
+    lane_offsets<REQ>(ra, v, num_items, byte_offset, offset_y);
     bool is_nan;
     int32_t n1 = 0;
     {
         composite_t a[N];
-        load_composites<N, EXACT>(a, members_x, cs, bytes, byte_offset);
+        load_composites<N, EXACT, REQ>(a, members_x, cs, bytes, byte_offset);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<N>::sort(a);
         __builtin_amdgcn_sched_barrier(0);
@@ -200,7 +229,6 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
     }
     __builtin_amdgcn_sched_barrier(0);
     uint32_t nan_flag = is_nan ? 1u : 0u;
-    uint32_t offset_y = byte_offset;
     order_after(nan_flag, offset_y);  // the Y side starts after the X composites are dead
     int32_t n1_pinned = n1;
     uint32_t lane_b = uint32_t(lane);
@@ -208,7 +236,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
     is_nan = nan_flag != 0u;
     n1 = n1_pinned;
     composite_t b[N];  // (Y key, member)
-    load_composites<N, EXACT>(b, members_y, cs, bytes, offset_y);
+    load_composites<N, EXACT, REQ>(b, members_y, cs, bytes, offset_y);
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(b);
     __builtin_amdgcn_sched_barrier(0);
@@ -274,8 +302,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
     const int32_t n0 = (n * (n - 1)) / 2;
     const int32_t numerator = n0 - n1 - n2 - 2 * discordant;
     float res = float(numerator) / (sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2)));
+    if (REQ && ra.use_abs) res = fabsf(res);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
-    if (v < num_voxels) store_result_nt(out + v, res);
+    if (v < num_items) store_result_nt(out + v, res);
 }
 
 namespace {
@@ -291,19 +320,74 @@ void launch_exact_or_guarded(int cs, Args... args) {
 template <int N, bool EXACT, int WAVES>
 struct SpearmanLauncher {
     static void launch(const float* const* mx, const float* const* my, float* out, size_t num_voxels, int cs,
-                       hipStream_t s) {
-        hipLaunchKernelGGL((spearman_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64),
-                           0, s, mx, my, out, num_voxels, cs);
+                       size_t num_items, RequestArgs ra, hipStream_t s) {
+        const dim3 grid(unsigned((num_items + 63) / 64));
+        if (ra.requests) {
+            if constexpr (!EXACT)  // request mode: the guarded instantiations only
+                hipLaunchKernelGGL((spearman_symmetric_kernel<N, false, WAVES, true>), grid, dim3(64), 0, s, mx, my, out,
+                                   num_voxels, cs, num_items, ra);
+        } else {
+            hipLaunchKernelGGL((spearman_symmetric_kernel<N, EXACT, WAVES, false>), grid, dim3(64), 0, s, mx, my, out,
+                               num_voxels, cs, num_items, ra);
+        }
     }
 };
 template <int N, bool EXACT, int WAVES>
 struct KendallLauncher {
     static void launch(const float* const* mx, const float* const* my, float* out, size_t num_voxels, int cs,
-                       hipStream_t s) {
-        hipLaunchKernelGGL((kendall_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64),
-                           0, s, mx, my, out, num_voxels, cs);
+                       size_t num_items, RequestArgs ra, hipStream_t s) {
+        const dim3 grid(unsigned((num_items + 63) / 64));
+        if (ra.requests) {
+            if constexpr (!EXACT)
+                hipLaunchKernelGGL((kendall_symmetric_kernel<N, false, WAVES, true>), grid, dim3(64), 0, s, mx, my, out,
+                                   num_voxels, cs, num_items, ra);
+        } else {
+            hipLaunchKernelGGL((kendall_symmetric_kernel<N, EXACT, WAVES, false>), grid, dim3(64), 0, s, mx, my, out,
+                               num_voxels, cs, num_items, ra);
+        }
     }
 };
+
+}  // namespace
+
+namespace {
+
+// exact = may the unguarded instantiation be used (field mode with cs a multiple of 16)
+hipError_t launch_sorted_rank(const float* const* d_members_x, const float* const* d_members_y, int cs, size_t num_voxels,
+                              int measure, float* d_out, size_t num_items, const RequestArgs& ra, hipStream_t s) {
+    const int n = (cs + 15) / 16 * 16;
+    const int cs_sel = ra.requests ? -1 : cs;  // request mode: never the unguarded instantiation
+#define CRF_SYM_CASE(L, N, W) \
+    case N: launch_exact_or_guarded<L, N, W>(cs_sel, d_members_x, d_members_y, d_out, num_voxels, cs, num_items, ra, s); break
+    if (measure == 1) {
+        switch (n) {
+            CRF_SYM_CASE(SpearmanLauncher, 16, 4);
+            CRF_SYM_CASE(SpearmanLauncher, 32, 3);
+            CRF_SYM_CASE(SpearmanLauncher, 48, 2);
+            CRF_SYM_CASE(SpearmanLauncher, 64, 2);
+            CRF_SYM_CASE(SpearmanLauncher, 80, 1);
+            CRF_SYM_CASE(SpearmanLauncher, 96, 1);
+            CRF_SYM_CASE(SpearmanLauncher, 112, 1);
+            CRF_SYM_CASE(SpearmanLauncher, 128, 1);
+            default: return hipErrorNotSupported;
+        }
+    } else {
+        switch (n) {
+            CRF_SYM_CASE(KendallLauncher, 16, 4);
+            CRF_SYM_CASE(KendallLauncher, 32, 3);
+            CRF_SYM_CASE(KendallLauncher, 48, 2);
+            CRF_SYM_CASE(KendallLauncher, 64, 2);
+            CRF_SYM_CASE(KendallLauncher, 80, 1);
+            CRF_SYM_CASE(KendallLauncher, 96, 1);
+            CRF_SYM_CASE(KendallLauncher, 112, 1);
+            CRF_SYM_CASE(KendallLauncher, 128, 1);
+            default: return hipErrorNotSupported;
+        }
+    }
+#undef CRF_SYM_CASE
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // cs in [2, 128]; measure 1 Spearman, 2 Kendall, 3 / 5 binned MI / its correlation coefficient; hipErrorNotSupported
@@ -312,39 +396,23 @@ hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float*
                                    size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
                                    float max_y, const double* d_tables, float* d_out, hipStream_t s) {
     if (cs < 2 || cs > kMaxSortMembers) return hipErrorNotSupported;
-    const int n = (cs + 15) / 16 * 16;
-#define CRF_SYM_CASE(L, N, W, ...) \
-    case N: launch_exact_or_guarded<L, N, W>(cs, __VA_ARGS__); break
-    if (measure == 1) {
-        switch (n) {
-            CRF_SYM_CASE(SpearmanLauncher, 16, 4, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 32, 3, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 48, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 64, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 80, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 96, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(SpearmanLauncher, 112, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            default: launch_exact_or_guarded<SpearmanLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-        }
-    } else if (measure == 2) {
-        switch (n) {
-            CRF_SYM_CASE(KendallLauncher, 16, 4, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 32, 3, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 48, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 64, 2, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 80, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 96, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            CRF_SYM_CASE(KendallLauncher, 112, 1, d_members_x, d_members_y, d_out, num_voxels, cs, s);
-            default: launch_exact_or_guarded<KendallLauncher, 128, 1>(cs, d_members_x, d_members_y, d_out, num_voxels, cs, s); break;
-        }
-    } else if (measure == 3 || measure == 5) {
+    if (measure == 3 || measure == 5)
         return launch_sorted_symmetric_binned(d_members_x, d_members_y, cs, num_voxels, measure, num_bins, min_x, max_x,
                                               min_y, max_y, d_tables, d_out, s);
-    } else {
-        return hipErrorNotSupported;
-    }
-#undef CRF_SYM_CASE
-    return hipGetLastError();
+    if (measure != 1 && measure != 2) return hipErrorNotSupported;
+    return launch_sorted_rank(d_members_x, d_members_y, cs, num_voxels, measure, d_out, num_voxels,
+                              RequestArgs{nullptr, 0, 0, 0}, s);
+}
+
+// Pair requests (crf_compute_requests) through the same kernels: Spearman / Kendall, cs in [2, 128]; X = members_i at
+// voxel i, Y = members_j at voxel j of each request; hipErrorNotSupported otherwise (-> pair_request_kernel)
+hipError_t launch_sorted_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
+                                  size_t num_voxels, const uint32_t* d_requests, size_t num_requests, int measure,
+                                  int use_abs, float* d_out, hipStream_t s) {
+    if (cs < 2 || cs > kMaxSortMembers || (measure != 1 && measure != 2) || !d_requests) return hipErrorNotSupported;
+    if (num_requests == 0) return hipSuccess;
+    return launch_sorted_rank(d_members_i, d_members_j, cs, num_voxels, measure, d_out, num_requests,
+                              RequestArgs{d_requests, xs, ys, use_abs}, s);
 }
 
 }  // namespace crf

@@ -49,14 +49,18 @@ def test_oracle_pairs_vs_golden(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cs", [2, 16, 64, 100, 300])
+@pytest.mark.parametrize("cs", [2, 16, 17, 48, 64, 65, 100, 128, 300])
 def test_gpu_pair_requests(engine, oracle, cs):
-    ens, pairs, ii, jj = _case(cs, 900 + cs)
+    ens, pairs, ii, jj = _case(cs, 900 + cs, n=400 + cs % 7)      # request counts that are not a multiple of 64
     _, zs, ys, xs = ens.shape
     engine.set_grid(xs, ys, zs, cs)
     engine.upload_members(ens)
     for m, om in ((Measure.PEARSON, 0), (Measure.SPEARMAN, 1), (Measure.KENDALL, 2)):
         assert_bit_exact(engine.compute_requests(m, pairs), oracle.pair_requests(om, ens, ii, jj), f"gpu pairs {m.name} cs={cs}")
+        if om > 0:     # Spearman / Kendall: the sort-based two-vector kernels up to 128 members
+            assert engine.last_kernel_name() == ("sorted_request_kernel" if cs <= 128 else "pair_request_kernel")
+            assert_bit_exact(engine.compute_requests(m, pairs, absolute_value=True),
+                             oracle.pair_requests(om, ens, ii, jj, use_abs=True), f"gpu pairs |{m.name}| cs={cs}")
     k = min(3, max(cs - 1, 1))
     assert_close(engine.compute_requests(Measure.MUTUAL_INFORMATION_BINNED, pairs, num_bins=80),
                  oracle.pair_requests(3, ens, ii, jj, num_bins=80), f"gpu pairs binned cs={cs}")
