@@ -774,7 +774,12 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
     // Spearman / Kendall up to 128 members: the sort-based two-vector kernels (kernels_symmetric.hip) in request mode
     hipError_t e = hipErrorNotSupported;
     const char* force_generic = getenv("CRF_REQUESTS_GENERIC");  // tuning / tests: the counting kernel
-    if (!(force_generic && *force_generic == '1')) {
+    if (!(force_generic && *force_generic == '1') && p->measure == CRF_PEARSON) {
+        e = crf::launch_pearson_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                         static_cast<const uint32_t*>(device_requests), num_requests, a.use_abs,
+                                         static_cast<float*>(device_out), s);
+        c->last_kernel = "pearson_request_kernel";
+    } else if (!(force_generic && *force_generic == '1')) {
         e = crf::launch_sorted_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
                                         static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
                                         a.use_abs, static_cast<float*>(device_out), s);

@@ -276,23 +276,38 @@ __global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_lds_kernel(const f
 // (Correlation.cpp:141-174), nothing to hoist.  2*cs loads per voxel (8*cs + 4 algorithmic bytes), both sides in
 // registers.  Same guarded-slot scheme as pearson_reg_kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int CS_PAD, bool EXACT, int MIN_WAVES>
+// REQ: pair-request mode (crf_compute_requests): item r works on request r = {xi, yi, zi, i, xj, yj, zj, j}
+// (HEBChart.hpp:166-168), X = the members at voxel i, Y = the members at voxel j; default cache policy (requests
+// revisit voxels); `requests`, `xs`, `ys`, `use_abs` are unused in field mode, where num_items = num_voxels.
+template <int CS_PAD, bool EXACT, int MIN_WAVES, bool REQ = false>
 __global__ __launch_bounds__(256, MIN_WAVES) void pearson_symmetric_kernel(const float* const* __restrict__ members_x,
                                                                            const float* const* __restrict__ members_y,
                                                                            float* __restrict__ out,
-                                                                           uint32_t num_voxels, int cs) {
+                                                                           uint32_t num_voxels, int cs,
+                                                                           const uint32_t* __restrict__ requests,
+                                                                           uint32_t num_items, int xs, int ys,
+                                                                           int use_abs) {
     constexpr int kFirstGuarded = EXACT ? CS_PAD : CS_PAD - 16;
     const auto is_member = [cs](int e) { return e < kFirstGuarded || e < cs; };
     const uint32_t v0 = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t byte_offset = v0 * 4u;
+    uint32_t offset_x = v0 * 4u, offset_y = v0 * 4u;
+    if constexpr (REQ) {
+        offset_x = offset_y = kOutOfRangeOffset;  // items past the end read 0 and store nothing
+        if (v0 < num_items) {
+            const uint32_t* q = requests + size_t(v0) * 8;
+            offset_x = ((q[2] * uint32_t(ys) + q[1]) * uint32_t(xs) + q[0]) * 4u;  // IDXS
+            offset_y = ((q[6] * uint32_t(ys) + q[5]) * uint32_t(xs) + q[4]) * 4u;
+        }
+    }
     const uint32_t bytes = num_voxels * 4u;
     float x[CS_PAD], y[CS_PAD];
 #pragma unroll
     for (int e = 0; e < CS_PAD; e++) {
         const int slot = (e < kFirstGuarded || e < cs) ? e : cs - 1;
-        const uint32_t off = is_member(e) ? byte_offset : kOutOfRangeOffset;
-        x[e] = load_member_nt(members_x[slot], bytes, off);
-        y[e] = load_member_nt(members_y[slot], bytes, off);
+        const uint32_t off_x = is_member(e) ? offset_x : kOutOfRangeOffset;
+        const uint32_t off_y = is_member(e) ? offset_y : kOutOfRangeOffset;
+        x[e] = REQ ? load_member_cached(members_x[slot], bytes, off_x) : load_member_nt(members_x[slot], bytes, off_x);
+        y[e] = REQ ? load_member_cached(members_y[slot], bytes, off_y) : load_member_nt(members_y[slot], bytes, off_y);
     }
     const float n = float(cs);
     const float invN = 1.0f / n;
@@ -325,7 +340,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void pearson_symmetric_kernel(const
         for (int e = 0; e < CS_PAD; e++)
             r += (invNm1 * (is_member(e) ? x[e] / sdX : 0.0f)) * (is_member(e) ? y[e] / sdY : 0.0f);
     }
-    if (v0 < num_voxels) store_result_nt(out + v0, r);
+    if (REQ && use_abs) r = fabsf(r);
+    if (v0 < num_items) store_result_nt(out + v0, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -523,21 +539,57 @@ void launch_symmetric(const float* const* mx, const float* const* my, int cs, si
         if (env_int("CRF_PEARSON_WAVES", 2) == 2) {
             if (cs == CS_PAD)
                 hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, true, 2>), dim3(blocks), dim3(256), 0, s, mx, my,
-                                   d_out, uint32_t(num_voxels), cs);
+                                   d_out, uint32_t(num_voxels), cs, nullptr, uint32_t(num_voxels), 0, 0, 0);
             else
                 hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, false, 2>), dim3(blocks), dim3(256), 0, s, mx, my,
-                                   d_out, uint32_t(num_voxels), cs);
+                                   d_out, uint32_t(num_voxels), cs, nullptr, uint32_t(num_voxels), 0, 0, 0);
             return;
         }
     }
     if (cs == CS_PAD)
         hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, true, kMinWaves>), dim3(blocks), dim3(256), 0, s, mx, my,
-                           d_out, uint32_t(num_voxels), cs);
+                           d_out, uint32_t(num_voxels), cs, nullptr, uint32_t(num_voxels), 0, 0, 0);
     else
         hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, false, kMinWaves>), dim3(blocks), dim3(256), 0, s, mx, my,
-                           d_out, uint32_t(num_voxels), cs);
+                           d_out, uint32_t(num_voxels), cs, nullptr, uint32_t(num_voxels), 0, 0, 0);
 }
 }  // namespace
+
+namespace {
+template <int CS_PAD>
+void launch_symmetric_requests(const float* const* mi, const float* const* mj, int cs, size_t num_voxels,
+                               const uint32_t* d_requests, size_t num_requests, int xs, int ys, int use_abs, float* d_out,
+                               hipStream_t s) {
+    constexpr int kMinWaves = CS_PAD <= 32 ? 4 : (CS_PAD <= 96 ? 2 : 1);
+    hipLaunchKernelGGL((pearson_symmetric_kernel<CS_PAD, false, kMinWaves, true>), dim3(unsigned((num_requests + 255) / 256)),
+                       dim3(256), 0, s, mi, mj, d_out, uint32_t(num_voxels), cs, d_requests, uint32_t(num_requests), xs, ys,
+                       use_abs);
+}
+}  // namespace
+
+// Pearson pair requests through the two-vector register kernel: 2 <= cs <= kMaxSymmetricRegisterMembers, fewer than
+// 2^32 requests; hipErrorNotSupported otherwise (-> pair_request_kernel)
+hipError_t launch_pearson_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
+                                   size_t num_voxels, const uint32_t* d_requests, size_t num_requests, int use_abs,
+                                   float* d_out, hipStream_t s) {
+    if (cs < 2 || cs > kMaxSymmetricRegisterMembers || !d_requests || num_requests >= (size_t(1) << 32))
+        return hipErrorNotSupported;
+    if (num_requests == 0) return hipSuccess;
+#define CRF_REQ_CASE(I, N) \
+    case I: launch_symmetric_requests<N>(d_members_i, d_members_j, cs, num_voxels, d_requests, num_requests, xs, ys, use_abs, d_out, s); break
+    switch ((cs + 15) / 16) {
+        CRF_REQ_CASE(1, 16);
+        CRF_REQ_CASE(2, 32);
+        CRF_REQ_CASE(3, 48);
+        CRF_REQ_CASE(4, 64);
+        CRF_REQ_CASE(5, 80);
+        CRF_REQ_CASE(6, 96);
+        CRF_REQ_CASE(7, 112);
+        default: launch_symmetric_requests<128>(d_members_i, d_members_j, cs, num_voxels, d_requests, num_requests, xs, ys, use_abs, d_out, s); break;
+    }
+#undef CRF_REQ_CASE
+    return hipGetLastError();
+}
 
 hipError_t launch_pearson_symmetric(const float* const* d_members_ref, const float* const* d_members_query, int cs,
                                     size_t num_voxels, float* d_out, hipStream_t s) {

@@ -57,6 +57,8 @@ def test_gpu_pair_requests(engine, oracle, cs):
     engine.upload_members(ens)
     for m, om in ((Measure.PEARSON, 0), (Measure.SPEARMAN, 1), (Measure.KENDALL, 2)):
         assert_bit_exact(engine.compute_requests(m, pairs), oracle.pair_requests(om, ens, ii, jj), f"gpu pairs {m.name} cs={cs}")
+        if om == 0:    # Pearson: the two-vector register kernel up to 128 members
+            assert engine.last_kernel_name() == ("pearson_request_kernel" if cs <= 128 else "pair_request_kernel")
         if om > 0:     # Spearman / Kendall: the sort-based two-vector kernels up to 128 members
             assert engine.last_kernel_name() == ("sorted_request_kernel" if cs <= 128 else "pair_request_kernel")
             assert_bit_exact(engine.compute_requests(m, pairs, absolute_value=True),
