@@ -779,6 +779,11 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
                                          static_cast<const uint32_t*>(device_requests), num_requests, a.use_abs,
                                          static_cast<float*>(device_out), s);
         c->last_kernel = "pearson_request_kernel";
+    } else if (!(force_generic && *force_generic == '1') && (p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC)) {
+        e = crf::launch_sorted_requests_binned(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+                                               static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
+                                               p->num_bins, a.use_abs, c->d_tables, static_cast<float*>(device_out), s);
+        c->last_kernel = "sorted_request_kernel";
     } else if (!(force_generic && *force_generic == '1')) {
         e = crf::launch_sorted_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
                                         static_cast<const uint32_t*>(device_requests), num_requests, p->measure,

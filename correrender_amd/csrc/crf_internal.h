@@ -149,6 +149,10 @@ size_t direct_symmetric_workspace_bytes(int cs, size_t num_voxels, int measure);
 hipError_t launch_sorted_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
                                    size_t num_voxels, int measure, int num_bins, float min_x, float max_x, float min_y,
                                    float max_y, const double* d_tables, float* d_out, hipStream_t s);
+hipError_t launch_sorted_requests_binned(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs,
+                                         int ys, size_t num_voxels, const uint32_t* d_requests, size_t num_requests,
+                                         int measure, int num_bins, int use_abs, const double* d_tables, float* d_out,
+                                         hipStream_t s);
 hipError_t launch_pearson_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,
                                    size_t num_voxels, const uint32_t* d_requests, size_t num_requests, int use_abs,
                                    float* d_out, hipStream_t s);

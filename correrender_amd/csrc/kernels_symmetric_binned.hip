@@ -26,12 +26,22 @@ struct SymmetricSortBinnedArgs {
     int to_cc;
 };
 
-template <int N, bool EXACT, int MIN_WAVES>
+// REQ: pair-request mode (crf_compute_requests; request layout {xi, yi, zi, i, xj, yj, zj, j}, HEBChart.hpp:166-168):
+// X = the members at voxel i, Y = the members at voxel j, both normalised with the PAIR's own extrema over the 2 cs
+// values (HEBChartCorrelation.cpp:493-600), cached loads, optional |.|.
+struct BinnedRequestArgs {
+    const uint32_t* requests;
+    int xs, ys;
+    int use_abs;
+};
+
+template <int N, bool EXACT, int MIN_WAVES, bool REQ = false>
 __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const float* const* __restrict__ members_x,
                                                                          const float* const* __restrict__ members_y,
                                                                          const double* __restrict__ tableT,
                                                                          float* __restrict__ out, size_t num_voxels,
-                                                                         int cs, SymmetricSortBinnedArgs ba) {
+                                                                         int cs, SymmetricSortBinnedArgs ba,
+                                                                         size_t num_items, BinnedRequestArgs ra) {
     __shared__ double T[N + 1];  // T[c] = (c/cs) ln(c/cs), T[0] = 0
     __shared__ uint16_t codes[N * 64];
     constexpr int SURE = sure_slots<N>();
@@ -39,7 +49,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
     for (int i = lane; i <= N; i += 64) T[i] = i <= cs ? tableT[i] : 0.0;
     __syncthreads();
     const size_t v = size_t(blockIdx.x) * 64 + lane;
-    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const auto is_member = [cs](int e) { return EXACT || e < SURE || e < cs; };
     const float range_x = ba.max_x - ba.min_x, range_y = ba.max_y - ba.min_y;
     const double nbd = double(ba.num_bins);
@@ -47,6 +57,45 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
     uint32_t a[N];
     bool is_nan = false;
     int total = 0;
+    if constexpr (REQ) {
+        uint32_t offset_x = kOutOfRangeOffset, offset_y = kOutOfRangeOffset;  // items past the end read 0, store nothing
+        if (v < num_items) {
+            const uint32_t* q = ra.requests + v * 8;
+            offset_x = ((q[2] * uint32_t(ra.ys) + q[1]) * uint32_t(ra.xs) + q[0]) * 4u;  // IDXS
+            offset_y = ((q[6] * uint32_t(ra.ys) + q[5]) * uint32_t(ra.xs) + q[4]) * 4u;
+        }
+        float x[N], y[N];
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            x[e] = load_member_cached(members_x[is_member(e) ? e : cs - 1], bytes, is_member(e) ? offset_x : kOutOfRangeOffset);
+            y[e] = load_member_cached(members_y[is_member(e) ? e : cs - 1], bytes, is_member(e) ? offset_y : kOutOfRangeOffset);
+        }
+        float mn = __uint_as_float(0x7F7FFFFFu), mx = __uint_as_float(0xFF7FFFFFu);  // the pair's own extrema
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            if (is_member(e)) {
+                mn = fminf(mn, fminf(x[e], y[e]));
+                mx = fmaxf(mx, fmaxf(x[e], y[e]));
+            }
+        }
+        const float range = mx - mn;
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool member = is_member(e);
+            is_nan |= member && ((x[e] != x[e]) || (y[e] != y[e]));
+            const float x01 = (x[e] - mn) / range, y01 = (y[e] - mn) / range;
+            int b0 = int(double(x01) * nbd), b1 = int(double(y01) * nbd);
+            b0 = b0 < 0 ? 0 : (b0 > nb - 1 ? nb - 1 : b0);
+            b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
+            const bool valid = member && (x01 == x01) && (y01 == y01);
+            a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
+            total += valid ? 1 : 0;
+        }
+        uint32_t nan_flag = is_nan ? 1u : 0u;
+        asm volatile("" : "+v"(nan_flag));
+        is_nan = nan_flag != 0u;
+    } else {
+    const uint32_t byte_offset = uint32_t(v) * 4u;
     {
         float x[N];
 #pragma unroll
@@ -87,6 +136,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
         uint32_t nan_flag = is_nan ? 1u : 0u;
         asm volatile("" : "+v"(nan_flag));
         is_nan = nan_flag != 0u;
+    }
     }
     const bool slow = total != cs;
     const bool any_slow = __any(slow);
@@ -185,9 +235,10 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
     }
     float res = float(mi);
     if (ba.to_cc) res = mi_to_cc(res);
+    if (REQ && ra.use_abs) res = fabsf(res);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (cs == 1) res = 1.0f;
-    if (v < num_voxels) store_result_nt(out + v, res);
+    if (v < num_items) store_result_nt(out + v, res);
 }
 
 namespace {
@@ -203,11 +254,48 @@ void launch_exact_or_guarded(int cs, Args... args) {
 template <int N, bool EXACT, int WAVES>
 struct BinnedLauncher {
     static void launch(const float* const* mx, const float* const* my, const double* tableT, float* out,
-                       size_t num_voxels, int cs, SymmetricSortBinnedArgs ba, hipStream_t s) {
-        hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES>), dim3(unsigned((num_voxels + 63) / 64)), dim3(64), 0,
-                           s, mx, my, tableT, out, num_voxels, cs, ba);
+                       size_t num_voxels, int cs, SymmetricSortBinnedArgs ba, size_t num_items, BinnedRequestArgs ra,
+                       hipStream_t s) {
+        const dim3 grid(unsigned((num_items + 63) / 64));
+        if (ra.requests) {
+            // request mode holds both vectors' samples at once (2 N + N registers): one wave fewer than field mode
+            constexpr int RW = WAVES > 1 ? WAVES - 1 : 1;
+            if constexpr (!EXACT)
+                hipLaunchKernelGGL((binned_symmetric_kernel<N, false, RW, true>), grid, dim3(64), 0, s, mx, my, tableT,
+                                   out, num_voxels, cs, ba, num_items, ra);
+        } else {
+            hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES, false>), grid, dim3(64), 0, s, mx, my, tableT,
+                               out, num_voxels, cs, ba, num_items, ra);
+        }
     }
 };
+
+}  // namespace
+
+namespace {
+
+hipError_t launch_sorted_binned(const float* const* d_members_x, const float* const* d_members_y, int cs,
+                                size_t num_voxels, const SymmetricSortBinnedArgs& ba, const double* d_tables, float* d_out,
+                                size_t num_items, const BinnedRequestArgs& ra, hipStream_t s) {
+    const int n = (cs + 15) / 16 * 16;
+    const int cs_sel = ra.requests ? -1 : cs;  // request mode: the guarded instantiations only
+    const double* tableT = d_tables + (cs + 1);
+#define CRF_SYM_CASE(N, W) \
+    case N: launch_exact_or_guarded<BinnedLauncher, N, W>(cs_sel, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, num_items, ra, s); break
+    switch (n) {
+        CRF_SYM_CASE(16, 4);
+        CRF_SYM_CASE(32, 3);
+        CRF_SYM_CASE(48, 3);
+        CRF_SYM_CASE(64, 3);
+        CRF_SYM_CASE(80, 2);
+        CRF_SYM_CASE(96, 2);
+        CRF_SYM_CASE(112, 2);
+        CRF_SYM_CASE(128, 2);
+        default: return hipErrorNotSupported;
+    }
+#undef CRF_SYM_CASE
+    return hipGetLastError();
+}
 
 }  // namespace
 
@@ -215,26 +303,23 @@ hipError_t launch_sorted_symmetric_binned(const float* const* d_members_x, const
                                           size_t num_voxels, int measure, int num_bins, float min_x, float max_x,
                                           float min_y, float max_y, const double* d_tables, float* d_out, hipStream_t s) {
     if (cs < 2 || cs > kMaxSortMembers || (measure != 3 && measure != 5)) return hipErrorNotSupported;
-    const int n = (cs + 15) / 16 * 16;
-#define CRF_SYM_CASE(L, N, W, ...) \
-    case N: launch_exact_or_guarded<L, N, W>(cs, __VA_ARGS__); break
-    {
-        if (num_bins < 1 || num_bins > 255) return hipErrorNotSupported;
-        const SymmetricSortBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
-        const double* tableT = d_tables + (cs + 1);
-        switch (n) {
-            CRF_SYM_CASE(BinnedLauncher, 16, 4, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 32, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 48, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 64, 3, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 80, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 96, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            CRF_SYM_CASE(BinnedLauncher, 112, 2, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s);
-            default: launch_exact_or_guarded<BinnedLauncher, 128, 2>(cs, d_members_x, d_members_y, tableT, d_out, num_voxels, cs, ba, s); break;
-        }
-    }
-#undef CRF_SYM_CASE
-    return hipGetLastError();
+    if (num_bins < 1 || num_bins > 255) return hipErrorNotSupported;
+    const SymmetricSortBinnedArgs ba{num_bins, min_x, max_x, min_y, max_y, measure == 5};
+    return launch_sorted_binned(d_members_x, d_members_y, cs, num_voxels, ba, d_tables, d_out, num_voxels,
+                                BinnedRequestArgs{nullptr, 0, 0, 0}, s);
+}
+
+// binned MI / its correlation coefficient for pair requests; hipErrorNotSupported -> pair_request_kernel
+hipError_t launch_sorted_requests_binned(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs,
+                                         int ys, size_t num_voxels, const uint32_t* d_requests, size_t num_requests,
+                                         int measure, int num_bins, int use_abs, const double* d_tables, float* d_out,
+                                         hipStream_t s) {
+    if (cs < 2 || cs > kMaxSortMembers || (measure != 3 && measure != 5) || !d_requests) return hipErrorNotSupported;
+    if (num_bins < 1 || num_bins > 255) return hipErrorNotSupported;
+    if (num_requests == 0) return hipSuccess;
+    const SymmetricSortBinnedArgs ba{num_bins, 0.f, 0.f, 0.f, 0.f, measure == 5};
+    return launch_sorted_binned(d_members_i, d_members_j, cs, num_voxels, ba, d_tables, d_out, num_requests,
+                                BinnedRequestArgs{d_requests, xs, ys, use_abs}, s);
 }
 
 }  // namespace crf

@@ -66,6 +66,7 @@ def test_gpu_pair_requests(engine, oracle, cs):
     k = min(3, max(cs - 1, 1))
     assert_close(engine.compute_requests(Measure.MUTUAL_INFORMATION_BINNED, pairs, num_bins=80),
                  oracle.pair_requests(3, ens, ii, jj, num_bins=80), f"gpu pairs binned cs={cs}")
+    assert engine.last_kernel_name() == ("sorted_request_kernel" if 2 <= cs <= 128 else "pair_request_kernel")
     assert_close(engine.compute_requests(Measure.BINNED_MI_CORRELATION_COEFFICIENT, pairs, num_bins=40),
                  oracle.pair_requests(5, ens, ii, jj, num_bins=40), f"gpu pairs binned cc cs={cs}")
     assert_close(engine.compute_requests(Measure.MUTUAL_INFORMATION_KRASKOV, pairs, k=k),
