@@ -365,7 +365,7 @@ hipError_t launch_sorted_rank(const float* const* d_members_x, const float* cons
             CRF_SYM_CASE(SpearmanLauncher, 32, 3);
             CRF_SYM_CASE(SpearmanLauncher, 48, 2);
             CRF_SYM_CASE(SpearmanLauncher, 64, 2);
-            CRF_SYM_CASE(SpearmanLauncher, 80, 1);
+            CRF_SYM_CASE(SpearmanLauncher, 80, 2);
             CRF_SYM_CASE(SpearmanLauncher, 96, 1);
             CRF_SYM_CASE(SpearmanLauncher, 112, 1);
             CRF_SYM_CASE(SpearmanLauncher, 128, 1);
