@@ -42,6 +42,7 @@ class CrfRequest(C.Structure):
 FLAG_ABSOLUTE_VALUE = 1
 FLAG_SYMMETRIC = 2
 FLAG_REFERENCE_FROM_SECONDARY = 4
+FLAG_QUERY_FROM_SECONDARY = 8
 
 
 # every symbol include/corrfield.h declares: name -> (restype, argtypes)

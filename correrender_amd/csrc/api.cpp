@@ -770,28 +770,35 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, num_requests))) return r;
+    // two-field request mode: the j side reads the secondary members (CRF_FLAG_QUERY_FROM_SECONDARY)
+    const float* const* members_j = c->d_member_table;
+    if (p->flags & CRF_FLAG_QUERY_FROM_SECONDARY) {
+        if (c->sec_members.empty())
+            return fail(c, CRF_ERR_STATE, "CRF_FLAG_QUERY_FROM_SECONDARY needs secondary members (crf_upload_secondary_members)");
+        members_j = c->d_sec_table;
+    }
     const crf::PairArgs a{p->measure, p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) ? 1 : 0, 0, 0.f, 0.f, 0.f, 0.f};
     // Spearman / Kendall up to 128 members: the sort-based two-vector kernels (kernels_symmetric.hip) in request mode
     hipError_t e = hipErrorNotSupported;
     const char* force_generic = getenv("CRF_REQUESTS_GENERIC");  // tuning / tests: the counting kernel
     if (!(force_generic && *force_generic == '1') && p->measure == CRF_PEARSON) {
-        e = crf::launch_pearson_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+        e = crf::launch_pearson_requests(c->d_member_table, members_j, c->cs, c->xs, c->ys, c->num_voxels,
                                          static_cast<const uint32_t*>(device_requests), num_requests, a.use_abs,
                                          static_cast<float*>(device_out), s);
         c->last_kernel = "pearson_request_kernel";
     } else if (!(force_generic && *force_generic == '1') && (p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC)) {
-        e = crf::launch_sorted_requests_binned(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+        e = crf::launch_sorted_requests_binned(c->d_member_table, members_j, c->cs, c->xs, c->ys, c->num_voxels,
                                                static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
                                                p->num_bins, a.use_abs, c->d_tables, static_cast<float*>(device_out), s);
         c->last_kernel = "sorted_request_kernel";
     } else if (!(force_generic && *force_generic == '1')) {
-        e = crf::launch_sorted_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+        e = crf::launch_sorted_requests(c->d_member_table, members_j, c->cs, c->xs, c->ys, c->num_voxels,
                                         static_cast<const uint32_t*>(device_requests), num_requests, p->measure,
                                         a.use_abs, static_cast<float*>(device_out), s);
         c->last_kernel = "sorted_request_kernel";
     }
     if (e == hipErrorNotSupported) {
-        e = crf::launch_pair_requests(c->d_member_table, c->d_member_table, c->cs, c->xs, c->ys, c->num_voxels,
+        e = crf::launch_pair_requests(c->d_member_table, members_j, c->cs, c->xs, c->ys, c->num_voxels,
                                       static_cast<const uint32_t*>(device_requests), num_requests, a, c->d_tables,
                                       c->d_workspace, static_cast<float*>(device_out), s);
         c->last_kernel = "pair_request_kernel";

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import (FLAG_ABSOLUTE_VALUE, FLAG_REFERENCE_FROM_SECONDARY, FLAG_SYMMETRIC, CorrFieldError, CrfParams,
+from ._lib import (FLAG_ABSOLUTE_VALUE, FLAG_QUERY_FROM_SECONDARY, FLAG_REFERENCE_FROM_SECONDARY, FLAG_SYMMETRIC, CorrFieldError, CrfParams,
                    load_library)
 
 
@@ -254,9 +254,11 @@ class CorrField:
         if keep is not None:
             self._keep_ref = keep
 
-    def compute_requests(self, measure, pairs, *, k=None, num_bins=80, absolute_value=False) -> np.ndarray:
+    def compute_requests(self, measure, pairs, *, k=None, num_bins=80, absolute_value=False,
+                         query_from_secondary=False) -> np.ndarray:
         """Pair-request mode (the reference's CorrelationComputePass request mode / HEBChart::computeCorrelations):
-        `pairs` is an [n, 6] integer array of (xi, yi, zi, xj, yj, zj); returns n floats."""
+        `pairs` is an [n, 6] integer array of (xi, yi, zi, xj, yj, zj); returns n floats.  With
+        `query_from_secondary` the j side reads the secondary member set (two-field request mode)."""
         pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 6)
         xs, ys, _ = self.grid
         req = np.zeros((pairs.shape[0], 8), dtype=np.uint32)
@@ -265,7 +267,7 @@ class CorrField:
         req[:, 3] = (pairs[:, 2] * ys + pairs[:, 1]) * xs + pairs[:, 0]
         req[:, 7] = (pairs[:, 5] * ys + pairs[:, 4]) * xs + pairs[:, 3]
         p, _ = self._params(measure, None, k, 1, num_bins, None, None, None)
-        p.flags = FLAG_ABSOLUTE_VALUE if absolute_value else 0
+        p.flags = (FLAG_ABSOLUTE_VALUE if absolute_value else 0) | (FLAG_QUERY_FROM_SECONDARY if query_from_secondary else 0)
         out = np.empty(req.shape[0], dtype=np.float32)
         self._check(self._lib.crf_compute_requests(self._ctx, C.byref(p), C.c_void_p(req.ctypes.data), req.shape[0],
                                                    out.ctypes.data_as(C.POINTER(C.c_float))))

@@ -94,6 +94,11 @@ typedef struct crf_params {
  * (ref_x, ref_y, ref_z) -- referenceValues[c] = field2_c[IDXS(ref)], CorrelationCalculator.cpp:804-813 (for time-lag
  * correlations bind the secondary field's members of the lagged time step). */
 #define CRF_FLAG_REFERENCE_FROM_SECONDARY 4
+/* Pair requests over two fields (crf_compute_requests*): the i side of every request reads the primary members, the j
+ * side the SECONDARY members -- the request mode with setUseSecondaryFields(true) / setFieldBuffersSecondary
+ * (CorrelationCalculator.hpp:255-257, HEBChartCorrelation.cpp:1164-1169; scalarFieldsRef / scalarFieldsQuery in
+ * Data/Shaders/Correlation/ScalarFields.glsl:105-120).  Both member sets share the local grid. */
+#define CRF_FLAG_QUERY_FROM_SECONDARY 8
 
 /* One pair request: the estimator between the ensemble vectors of voxel (xi,yi,zi) and voxel (xj,yj,zj).  Same layout
  * as struct CorrelationRequestData {xi,yi,zi,i,xj,yj,zj,j} (src/Renderers/Diagram/HEBChart.hpp:166-168,
@@ -167,6 +172,7 @@ int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* d
  * CPU twin: Pearson/Spearman/Kendall as in the full-grid path but with both vectors per request; binned MI normalises
  * both vectors with the extrema of the pair (:556-566); Kraskov is KSG-1; MI-CC variants map sqrt(1-exp(-2 MI));
  * CRF_FLAG_ABSOLUTE_VALUE takes |.|; a NaN in either vector gives NaN (the CPU twin emits no entry for that pair).
+ * CRF_FLAG_QUERY_FROM_SECONDARY: the j side reads the secondary members (two-field request mode).
  * Read from params: measure, k, num_bins, flags. */
 int crf_compute_requests(crf_context* ctx, const crf_params* params, const crf_request* host_requests,
                          size_t num_requests, float* host_out);

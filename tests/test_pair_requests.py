@@ -92,3 +92,34 @@ def test_gpu_pair_requests_golden_and_errors(engine):
         engine.compute_requests(Measure.PEARSON, [[0, 0, 0, xs, 0, 0]])
     assert e.value.code == 1 and "outside" in e.value.message
     assert engine.compute_requests(Measure.PEARSON, np.zeros((0, 6), int)).size == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cs", [5, 32, 64, 100, 200])
+def test_gpu_two_field_pair_requests(engine, oracle, cs):
+    """Two-field request mode (setUseSecondaryFields, HEBChartCorrelation.cpp:1164-1169): the i side reads the first
+    field, the j side the second.  Expectation: the oracle's pair evaluation on the two fields stacked along z, with the
+    j indices moved into the second half."""
+    from correrender_amd import CorrFieldError
+    ens, pairs, ii, jj = _case(cs, 1700 + cs, n=333)
+    rng = np.random.default_rng(cs)
+    second = (0.5 * ens + rng.standard_normal(ens.shape)).astype(np.float32)
+    second[:, 0, 0, 1] = np.round(second[:, 0, 0, 1])
+    _, zs, ys, xs = ens.shape
+    stacked = np.concatenate([ens, second], axis=1)
+    jj2 = jj + xs * ys * zs
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    with pytest.raises(CorrFieldError):
+        engine.compute_requests(Measure.PEARSON, pairs, query_from_secondary=True)
+    engine.upload_secondary_members(second)
+    for m, om in ((Measure.PEARSON, 0), (Measure.SPEARMAN, 1), (Measure.KENDALL, 2)):
+        assert_bit_exact(engine.compute_requests(m, pairs, query_from_secondary=True),
+                         oracle.pair_requests(om, stacked, ii, jj2), f"two-field pairs {m.name} cs={cs}")
+    assert_close(engine.compute_requests(Measure.MUTUAL_INFORMATION_BINNED, pairs, num_bins=60, query_from_secondary=True),
+                 oracle.pair_requests(3, stacked, ii, jj2, num_bins=60), f"two-field pairs binned cs={cs}")
+    k = min(3, cs - 1)
+    assert_close(engine.compute_requests(Measure.MUTUAL_INFORMATION_KRASKOV, pairs, k=k, query_from_secondary=True),
+                 oracle.pair_requests(4, stacked, ii, jj2, k=k), f"two-field pairs kraskov cs={cs}")
+    # without the flag the second field is not read
+    assert_bit_exact(engine.compute_requests(Measure.KENDALL, pairs), oracle.pair_requests(2, ens, ii, jj), "one-field pairs")
