@@ -13,11 +13,14 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "crf_context.h"
 #include "crf_internal.h"
 
 namespace {
@@ -33,45 +36,6 @@ std::string fmt(const char* f, ...) {
 }
 }  // namespace
 
-struct crf_context {
-    int device = -1;
-    hipStream_t stream = nullptr;  // the context's own stream (used when the caller passes none)
-    std::string err;
-    int xs = 0, ys = 0, zs = 0, cs = 0;
-    size_t num_voxels = 0;
-    // members
-    void* owned_block = nullptr;  // one allocation holding every uploaded member (stride owned_stride floats)
-    size_t owned_stride = 0;
-    std::vector<const float*> members;  // cs device pointers (owned or borrowed)
-    const float** d_member_table = nullptr;
-    int max_vpt = 1;
-    // secondary members (second scalar field of the SEPARATE / SEPARATE_SYMMETRIC modes), optional
-    void* sec_owned_block = nullptr;
-    std::vector<const float*> sec_members;
-    const float** d_sec_table = nullptr;
-    bool sec_minmax_valid = false;
-    float sec_min_v = 0.f, sec_max_v = 0.f;
-    // scratch
-    float* d_ref = nullptr;    // cs reference values
-    float* d_prep = nullptr;   // crf::kPrepBytes
-    float* d_prep_slots = nullptr;  // CRF_PREPARED_SLOTS x crf::kPrepBytes, lazily (crf_prepare_device)
-    float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
-    double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
-    uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
-    unsigned char* d_workspace = nullptr;  // voxel tiles of the generic (cs > 128) kernels, lazily
-    size_t workspace_bytes = 0;
-    uint32_t* d_requests = nullptr;  // staging of host pair requests / their results, lazily
-    float* d_request_out = nullptr;
-    size_t request_capacity = 0;
-    uint32_t* d_minmax = nullptr;
-    bool minmax_valid = false;
-    float min_v = 0.f, max_v = 0.f;
-    // profiling
-    bool profiling = false;
-    std::vector<hipEvent_t> ev_free;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
-    std::string last_kernel;
-};
 
 namespace {
 
@@ -120,6 +84,7 @@ int install_member_table(crf_context* c) {
                               hipMemcpyHostToDevice, c->stream));
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     c->minmax_valid = false;
+    c->host_chunks = 0;  // the per-range pointer tables of the host-output path describe the old members
     return CRF_OK;
 }
 
@@ -158,6 +123,19 @@ std::vector<double> build_tables(int cs) {
         }
     }
     return t;
+}
+
+// psi(n) = -gamma + H_{n-1} at a positive integer, the same long-double accumulation as build_tables()
+double psi_int(int n) {
+    long double h = 0.0L;
+    for (int i = 1; i < n; i++) h += 1.0L / (long double)i;
+    return double(h - 0.577215664901532860606512090082402431L);
+}
+// the k-dependent constant of the KSG estimators: psi(k) (KSG-1, MutualInformation.cpp:438) or psi(k) - 1/k (KSG-2, :503)
+double kraskov_c_term(int k, int estimator) {
+    double c = psi_int(k);
+    if (estimator != 1) c -= 1.0 / double(k);
+    return c;
 }
 
 int check_ready(crf_context* c) {
@@ -245,6 +223,10 @@ void crf_destroy(crf_context* c) {
     if (c->d_requests) (void)hipFree(c->d_requests);
     if (c->d_request_out) (void)hipFree(c->d_request_out);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
+    if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
+    for (hipEvent_t e : c->chunk_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ev_pending) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -264,6 +246,7 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (n * sizeof(float) >= size_t(0xFFFFFFF0u))
         return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) of 4 GiB or more is not supported; shard it");
     if (int r = bind_device(c)) return r;
+    CRF_HIP(c, hipDeviceSynchronize());  // evaluations the caller left in flight on its own streams still read the scratch
     release_members(c);
     release_secondary(c);
     if (c->d_member_table) (void)hipFree(c->d_member_table);
@@ -274,6 +257,9 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_todo) (void)hipFree(c->d_todo);
     if (c->d_workspace) (void)hipFree(c->d_workspace);
+    if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
+    c->d_chunk_tables = nullptr;
+    c->host_chunks = 0;
     c->d_todo = nullptr;
     c->d_workspace = nullptr;
     c->workspace_bytes = 0;
@@ -286,6 +272,7 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     c->zs = zs;
     c->cs = cs;
     c->num_voxels = n;
+    c->alloc_voxels = n;
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_member_table), sizeof(float*) * size_t(cs)));
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ref), sizeof(float) * size_t(cs)));
     const std::vector<double> tables = build_tables(cs);
@@ -407,6 +394,7 @@ int crf_secondary_member_minmax(crf_context* c, float* out_min, float* out_max) 
 
 static int ensure_workspace(crf_context* c, size_t need) {
     if (need > c->workspace_bytes) {
+        CRF_HIP(c, hipDeviceSynchronize());  // an earlier evaluation on a caller stream may still use the old workspace
         if (c->d_workspace) (void)hipFree(c->d_workspace);
         c->d_workspace = nullptr;
         c->workspace_bytes = 0;
@@ -424,8 +412,9 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
         return fail(c, CRF_ERR_UNSUPPORTED, fmt("the symmetric mode supports at most %d members", crf::kMaxGenericMembers));
     if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
         return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
-    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || (p->k > c->cs && c->cs > 1)))
-        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+    // any k >= 1, like the reference (its k+1-nearest-neighbour query returns at most cs points; psi(k) itself is used)
+    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && p->k < 1)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be at least 1", p->k));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = take_event(c);
@@ -439,7 +428,7 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
     }
     if (p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) {
         e = crf::launch_mi_kraskov_symmetric(c->d_member_table, c->d_sec_table, c->cs, c->num_voxels, p->k,
-                                             p->measure == CRF_KMI_CC, c->d_tables, out, s);
+                                             kraskov_c_term(p->k, 1), p->measure == CRF_KMI_CC, c->d_tables, out, s);
         c->last_kernel = "kraskov_direct_kernel";
     }
     if (p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL || p->measure == CRF_MI_BINNED ||
@@ -462,7 +451,8 @@ static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hi
     }
     if (e == hipErrorNotSupported) {
         if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, c->num_voxels))) return r;
-        const crf::PairArgs a{p->measure, p->num_bins, p->k, 0, 1, p->min_ref, p->max_ref, p->min_query, p->max_query};
+        const crf::PairArgs a{p->measure, p->num_bins, p->k, 0, 1, p->min_ref, p->max_ref, p->min_query, p->max_query,
+                              kraskov_c_term(p->k > 0 ? p->k : 1, 1)};
         e = crf::launch_pair_requests(c->d_member_table, c->d_sec_table, c->cs, c->xs, c->ys, c->num_voxels, nullptr,
                                       c->num_voxels, a, c->d_tables, c->d_workspace, out, s);
         c->last_kernel = "pair_request_kernel";
@@ -527,28 +517,60 @@ int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
 // while the kernel that produces the result is still running, and the copy itself is the runtime's plain one.  (A
 // hand-rolled pipeline through a pinned staging buffer was measured slower than the runtime's copy: 2.45 vs 1.86 ms
 // into a touched buffer.)  Writing zeros ahead of the result is harmless: the buffer's content is ours to define.
-static int copy_result_to_host(crf_context* c, const float* d_src, float* host_out, size_t count) {
-    const size_t bytes = count * sizeof(float);
-    const char* plain = getenv("CRF_PLAIN_D2H");
-    if (bytes >= (size_t(8) << 20) && !(plain && *plain == '1')) {
+//
+// PageToucher faults the destination in, range by range in the order the ranges will be copied; wait(j) returns once
+// range j is resident.
+class PageToucher {
+public:
+    PageToucher(float* host_out, size_t count, size_t range_count, int ranges) {
+        const char* plain = getenv("CRF_PLAIN_D2H");
+        const size_t bytes = count * sizeof(float);
+        if (bytes < (size_t(8) << 20) || (plain && *plain == '1')) return;
         constexpr size_t kPage = 4096;
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t workers = std::min<size_t>(8, hw > 1 ? hw / 2 : 1);
+        const size_t workers = std::min<size_t>(16, hw > 1 ? hw / 2 : 1);
+        ranges_ = ranges;
+        done_ = std::make_unique<std::atomic<int>[]>(size_t(ranges));
+        for (int j = 0; j < ranges; j++) done_[size_t(j)].store(0, std::memory_order_relaxed);
+        workers_ = int(workers);
         char* base = reinterpret_cast<char*>(host_out);
-        const size_t per = (bytes / workers + kPage) & ~(kPage - 1);
-        std::vector<std::thread> pool;
-        pool.reserve(workers);
+        pool_.reserve(workers);
         for (size_t w = 0; w < workers; w++) {
-            const size_t lo = w * per, hi = std::min(bytes, lo + per);
-            if (lo >= hi) break;
-            pool.emplace_back([=]() {
-                for (size_t off = lo; off < hi; off += kPage) static_cast<volatile char*>(base)[off] = 0;
-                static_cast<volatile char*>(base)[hi - 1] = 0;
+            pool_.emplace_back([=]() {
+                for (int j = 0; j < ranges; j++) {
+                    const size_t r_lo = size_t(j) * range_count * sizeof(float);
+                    const size_t r_hi = std::min(bytes, r_lo + range_count * sizeof(float));
+                    const size_t per = ((r_hi - r_lo) / workers + kPage) & ~(kPage - 1);
+                    const size_t lo = r_lo + w * per, hi = std::min(r_hi, lo + per);
+                    if (lo < hi) {
+                        for (size_t off = lo; off < hi; off += kPage) static_cast<volatile char*>(base)[off] = 0;
+                        static_cast<volatile char*>(base)[hi - 1] = 0;
+                    }
+                    done_[size_t(j)].fetch_add(1, std::memory_order_release);
+                }
             });
         }
-        for (auto& t : pool) t.join();
     }
-    CRF_HIP(c, hipMemcpyAsync(host_out, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    void wait(int j) const {
+        if (!done_) return;
+        while (done_[size_t(j)].load(std::memory_order_acquire) < workers_) std::this_thread::yield();
+    }
+    ~PageToucher() {
+        for (auto& t : pool_) t.join();
+    }
+
+private:
+    std::unique_ptr<std::atomic<int>[]> done_;
+    std::vector<std::thread> pool_;
+    int ranges_ = 0, workers_ = 0;
+};
+
+static int copy_result_to_host(crf_context* c, const float* d_src, float* host_out, size_t count) {
+    {
+        PageToucher toucher(host_out, count, count, 1);
+        toucher.wait(0);
+    }
+    CRF_HIP(c, hipMemcpyAsync(host_out, d_src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     return CRF_OK;
 }
@@ -617,8 +639,8 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
                                                     crf::kMaxGenericMembers, c->cs));
         if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
             return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
-        if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || p->k > c->cs))
-            return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+        if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && p->k < 1)
+            return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be at least 1", p->k));
         if (p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) {  // O(cs) histogram kernel
             crf::BinnedArgs ba{p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query,
                                p->measure == CRF_BINNED_MI_CC};
@@ -633,7 +655,8 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             e = hipSuccess;  // too many bins for the LDS rows: the O(cs^2) kernel below
         }
         if (p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) {  // tile-free single-sweep top-K kernel
-            crf::KraskovArgs ka{p->k, p->kraskov_estimator_index == 2 ? 2 : 1, p->measure == CRF_KMI_CC};
+            const int est = p->kraskov_estimator_index == 2 ? 2 : 1;
+            crf::KraskovArgs ka{p->k, est, p->measure == CRF_KMI_CC, kraskov_c_term(p->k, est)};
             e = crf::launch_mi_kraskov_direct(c->d_member_table, c->cs, c->num_voxels, ref, ka, c->d_tables, prep, out, s,
                                               e0, e1, &info);
             if (e != hipErrorNotSupported) {
@@ -644,16 +667,10 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             }
             e = hipSuccess;  // k > 128 or tables beyond LDS: the repeated-minimum kernel below
         }
-        const size_t need = crf::generic_workspace_bytes(c->cs, c->num_voxels);
-        if (need > c->workspace_bytes) {
-            if (c->d_workspace) (void)hipFree(c->d_workspace);
-            c->d_workspace = nullptr;
-            c->workspace_bytes = 0;
-            CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_workspace), need));
-            c->workspace_bytes = need;
-        }
+        if (int r = ensure_workspace(c, crf::generic_workspace_bytes(c->cs, c->num_voxels))) return r;
         crf::GenericArgs ga{p->measure, p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query, p->k,
-                            p->kraskov_estimator_index == 2 ? 2 : 1};
+                            p->kraskov_estimator_index == 2 ? 2 : 1,
+                            kraskov_c_term(p->k > 0 ? p->k : 1, p->kraskov_estimator_index == 2 ? 2 : 1)};
         e = crf::launch_generic(c->d_member_table, c->cs, c->num_voxels, ref, ga, c->d_tables, prep, c->d_workspace,
                                 out, s, e0, e1, &info);
         c->last_kernel = info.kernel_name ? info.kernel_name : "";
@@ -670,7 +687,7 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Spearman supports at most %d members", crf::kMaxSortMembers));
             if (c->cs > 16 && !c->d_todo)
-                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
+                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->alloc_voxels + 1) * sizeof(uint32_t)));
             e = crf::launch_spearman(c->d_member_table, c->cs, c->num_voxels, ref, prep, c->d_todo, out, s, e0, e1,
                                      &info);
             break;
@@ -678,7 +695,7 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kendall supports at most %d members", crf::kMaxSortMembers));
             if (c->cs > 16 && !c->d_todo)
-                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->num_voxels + 1) * sizeof(uint32_t)));
+                CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->alloc_voxels + 1) * sizeof(uint32_t)));
             e = crf::launch_kendall(c->d_member_table, c->cs, c->num_voxels, ref, prep, c->d_todo, out, s, e0, e1,
                                     &info);
             break;
@@ -701,12 +718,11 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
         }
         case CRF_MI_KRASKOV:
         case CRF_KMI_CC: {
-            if (p->k < 1 || (p->k > c->cs && c->cs > 1))
-                return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+            if (p->k < 1) return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be at least 1", p->k));
             if (c->cs > crf::kMaxSortMembers)
                 return fail(c, CRF_ERR_UNSUPPORTED, fmt("Kraskov MI supports at most %d members", crf::kMaxSortMembers));
             const int est = p->kraskov_estimator_index == 2 ? 2 : 1;  // clamp as CorrelationCalculator.cpp:765
-            crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC};
+            crf::KraskovArgs a{p->k, est, p->measure == CRF_KMI_CC, kraskov_c_term(p->k, est)};
             e = crf::launch_mi_kraskov(c->d_member_table, c->cs, c->num_voxels, ref, a, c->d_tables, prep, out, s,
                                        e0, e1, &info);
             break;
@@ -745,13 +761,122 @@ int crf_prepare_device(crf_context* c, const crf_params* p, const void* device_r
 }
 
 int crf_compute(crf_context* c, const crf_params* p, float* host_out) {
-    if (int r = check_ready(c)) return r;
-    if (!host_out) return fail(c, CRF_ERR_ARGUMENT, "null output");
-    if (int r = bind_device(c)) return r;
-    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->num_voxels * sizeof(float)));
-    if (int r = crf_compute_device(c, p, nullptr, c->d_out, nullptr)) return r;
-    return copy_result_to_host(c, c->d_out, host_out, c->num_voxels);
+    return crf::compute_to_host(c, p, nullptr, host_out);
 }
+
+}  // extern "C"
+
+namespace {
+// The voxel ranges of a host-output evaluation: one member-pointer table per range (pointers advanced by the range's
+// first voxel), so that every per-voxel kernel can be launched on a range without knowing about ranges.
+int ensure_host_chunks(crf_context* c) {
+    if (c->host_chunks > 0) return CRF_OK;
+    const size_t n = c->alloc_voxels;
+    int chunks = 1;
+    const char* forced = getenv("CRF_HOST_CHUNKS");
+    if (forced && atoi(forced) >= 1) {
+        chunks = std::min(atoi(forced), kMaxHostChunks);
+    } else if (n * sizeof(float) >= (size_t(8) << 20)) {
+        chunks = kMaxHostChunks;
+    }
+    // range length: a multiple of 1024 voxels (4 KiB: keeps every range as aligned as the members themselves)
+    size_t per = (n + size_t(chunks) - 1) / size_t(chunks);
+    per = (per + 1023) & ~size_t(1023);
+    chunks = int((n + per - 1) / per);
+    std::vector<const float*> table(size_t(chunks) * size_t(c->cs));
+    for (int j = 0; j < chunks; j++)
+        for (int m = 0; m < c->cs; m++) table[size_t(j) * size_t(c->cs) + size_t(m)] = c->members[size_t(m)] + size_t(j) * per;
+    if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
+    c->d_chunk_tables = nullptr;
+    CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_tables), table.size() * sizeof(float*)));
+    CRF_HIP(c, hipMemcpy(c->d_chunk_tables, table.data(), table.size() * sizeof(float*), hipMemcpyHostToDevice));
+    if (!c->copy_stream) CRF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int j = 0; j < chunks; j++)
+        if (!c->chunk_done[j]) CRF_HIP(c, hipEventCreateWithFlags(&c->chunk_done[j], hipEventDisableTiming));
+    c->chunk_voxels = per;
+    c->host_chunks = chunks;
+    return CRF_OK;
+}
+
+// narrows the context to one voxel range for the duration of a launch; restores it on every exit path
+struct RangeScope {
+    crf_context* c;
+    const float** table;
+    size_t voxels;
+    int vpt;
+    explicit RangeScope(crf_context* ctx) : c(ctx), table(ctx->d_member_table), voxels(ctx->num_voxels), vpt(ctx->max_vpt) {}
+    void select(int j) {
+        c->d_member_table = c->d_chunk_tables + size_t(j) * size_t(c->cs);
+        c->num_voxels = std::min(c->chunk_voxels, c->alloc_voxels - size_t(j) * c->chunk_voxels);
+    }
+    ~RangeScope() {
+        c->d_member_table = table;
+        c->num_voxels = voxels;
+        c->max_vpt = vpt;
+    }
+};
+}  // namespace
+
+namespace crf {
+
+int gather_reference_to(crf_context* c, bool secondary, int x, int y, int z, float* device_out, hipStream_t s) {
+    if (int r = check_ready(c)) return r;
+    if (secondary && c->sec_members.empty()) return fail(c, CRF_ERR_STATE, "no secondary members are bound");
+    size_t voxel;
+    if (int r = ref_voxel(c, x, y, z, &voxel)) return r;
+    if (int r = bind_device(c)) return r;
+    CRF_HIP(c, launch_gather_reference(secondary ? c->d_sec_table : c->d_member_table, c->cs, voxel, device_out, s));
+    return CRF_OK;
+}
+
+// What calculateCpu(t, e, buffer) does, into the caller's host buffer (Calculator.hpp:123-124, VolumeData.cpp:1222-1226).
+// The reference-side preparation runs once; the per-voxel kernel is launched range by range on the context's stream and
+// each finished range is copied out on a second stream while the following ranges are still being evaluated, into
+// pages that a few host threads have faulted in meanwhile.
+int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out) {
+    if (int r = check_ready(c)) return r;
+    if (!host_out || !p) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (int r = bind_device(c)) return r;
+    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->alloc_voxels * sizeof(float)));
+    const bool ranged = !(p->flags & CRF_FLAG_SYMMETRIC) && p->prepared_slot == 0;
+    if (ranged)
+        if (int r = ensure_host_chunks(c)) return r;
+    if (!ranged || c->host_chunks <= 1) {
+        if (int r = crf_compute_device(c, p, device_reference_values, c->d_out, nullptr)) return r;
+        return copy_result_to_host(c, c->d_out, host_out, c->alloc_voxels);
+    }
+    const int chunks = c->host_chunks;
+    PageToucher toucher(host_out, c->alloc_voxels, c->chunk_voxels, chunks);
+    // 1. reference-side tables, once, from the whole-grid member table (the reference point indexes the whole grid)
+    if (int r = compute_impl(c, p, device_reference_values, nullptr, nullptr, 1u, -1)) return r;
+    // 2. per-voxel kernels, range by range
+    {
+        RangeScope scope(c);
+        for (int j = 0; j < chunks; j++) {
+            scope.select(j);
+            float* out = c->d_out + size_t(j) * c->chunk_voxels;
+            if (int r = compute_impl(c, p, nullptr, out, nullptr, 2u, -1)) return r;
+            if (p->flags & CRF_FLAG_ABSOLUTE_VALUE) CRF_HIP(c, launch_abs(out, c->num_voxels, c->stream));
+            CRF_HIP(c, hipEventRecord(c->chunk_done[j], c->stream));
+        }
+    }
+    // 3. copies, each as soon as its range is done and its destination pages are resident
+    for (int j = 0; j < chunks; j++) {
+        const size_t off = size_t(j) * c->chunk_voxels;
+        const size_t count = std::min(c->chunk_voxels, c->alloc_voxels - off);
+        toucher.wait(j);
+        CRF_HIP(c, hipStreamWaitEvent(c->copy_stream, c->chunk_done[j], 0));
+        CRF_HIP(c, hipMemcpyAsync(host_out + off, c->d_out + off, count * sizeof(float), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+    }
+    CRF_HIP(c, hipStreamSynchronize(c->copy_stream));
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    return CRF_OK;
+}
+
+}  // namespace crf
+
+extern "C" {
 
 int crf_compute_requests_device(crf_context* c, const crf_params* p, const void* device_requests, size_t num_requests,
                                 void* device_out, void* stream) {
@@ -765,8 +890,8 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
         return fail(c, CRF_ERR_UNSUPPORTED, fmt("pair requests support at most %d members", crf::kMaxGenericMembers));
     if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
         return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
-    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && (p->k < 1 || (p->k > c->cs && c->cs > 1)))
-        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs=%d]", p->k, c->cs));
+    if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && p->k < 1)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be at least 1", p->k));
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (int r = ensure_workspace(c, crf::pair_workspace_bytes(c->cs, num_requests))) return r;
@@ -777,7 +902,8 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
             return fail(c, CRF_ERR_STATE, "CRF_FLAG_QUERY_FROM_SECONDARY needs secondary members (crf_upload_secondary_members)");
         members_j = c->d_sec_table;
     }
-    const crf::PairArgs a{p->measure, p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) ? 1 : 0, 0, 0.f, 0.f, 0.f, 0.f};
+    const crf::PairArgs a{p->measure, p->num_bins, p->k, (p->flags & CRF_FLAG_ABSOLUTE_VALUE) ? 1 : 0, 0, 0.f, 0.f, 0.f, 0.f,
+                          kraskov_c_term(p->k > 0 ? p->k : 1, 1)};
     // Spearman / Kendall up to 128 members: the sort-based two-vector kernels (kernels_symmetric.hip) in request mode
     hipError_t e = hipErrorNotSupported;
     const char* force_generic = getenv("CRF_REQUESTS_GENERIC");  // tuning / tests: the counting kernel
@@ -915,12 +1041,8 @@ int crf_compute_dkl_device(crf_context* c, int estimator, int num_bins, int k, v
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (int r = ensure_workspace(c, crf::dkl_workspace_bytes(c->cs, estimator, num_bins, c->num_voxels))) return r;
     // psi(n) = -gamma + H_{n-1} (boost::math::digamma at positive integers, DKL.cpp:156)
-    auto psi = [](int n) {
-        long double h = 0.0L;
-        for (int i = 1; i < n; i++) h += 1.0L / (long double)i;
-        return double(h - 0.577215664901532860606512090082402431L);
-    };
-    const double knn_const = estimator == CRF_DKL_ENTROPY_KNN && c->cs > 1 ? psi(c->cs) - psi(k) + std::log(2.0) : 0.0;
+    const double knn_const =
+        estimator == CRF_DKL_ENTROPY_KNN && c->cs > 1 ? psi_int(c->cs) - psi_int(k) + std::log(2.0) : 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profiling) {
         e0 = take_event(c);
@@ -946,12 +1068,7 @@ int crf_compute_dkl(crf_context* c, int estimator, int num_bins, int k, float* h
 
 double crf_max_mutual_information_kraskov(int k, int cs) {
     if (k < 1 || cs < 1) return std::numeric_limits<double>::quiet_NaN();
-    auto psi = [](int n) {
-        long double h = 0.0L;
-        for (int i = 1; i < n; i++) h += 1.0L / (long double)i;
-        return double(h - 0.577215664901532860606512090082402431L);
-    };
-    return psi(cs) - psi(k);
+    return psi_int(cs) - psi_int(k);
 }
 
 size_t crf_tiled_element_count(int xs, int ys, int zs) {

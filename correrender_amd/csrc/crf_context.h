@@ -1,0 +1,72 @@
+// crf_context.h -- the state behind a crf_context (include/corrfield.h), shared by api.cpp and group.cpp.
+// Internal to libcorrfield.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/corrfield.h"
+#include "crf_internal.h"
+
+constexpr int kMaxHostChunks = 8;  // z-chunks of a host-output evaluation (kernel of chunk i+1 under the D2H of chunk i)
+
+struct crf_context {
+    int device = -1;
+    hipStream_t stream = nullptr;  // the context's own stream (used when the caller passes none)
+    std::string err;
+    int xs = 0, ys = 0, zs = 0, cs = 0;
+    size_t num_voxels = 0;
+    // members
+    void* owned_block = nullptr;  // one allocation holding every uploaded member (stride owned_stride floats)
+    size_t owned_stride = 0;
+    std::vector<const float*> members;  // cs device pointers (owned or borrowed)
+    const float** d_member_table = nullptr;
+    int max_vpt = 1;
+    // secondary members (second scalar field of the SEPARATE / SEPARATE_SYMMETRIC modes), optional
+    void* sec_owned_block = nullptr;
+    std::vector<const float*> sec_members;
+    const float** d_sec_table = nullptr;
+    bool sec_minmax_valid = false;
+    float sec_min_v = 0.f, sec_max_v = 0.f;
+    // scratch
+    float* d_ref = nullptr;    // cs reference values
+    float* d_prep = nullptr;   // crf::kPrepBytes
+    float* d_prep_slots = nullptr;  // CRF_PREPARED_SLOTS x crf::kPrepBytes, lazily (crf_prepare_device)
+    float* d_out = nullptr;    // num_voxels floats, lazily (crf_compute only)
+    double* d_tables = nullptr;  // psi / p ln p / noise tables for this member count (crf_internal.h)
+    uint32_t* d_todo = nullptr;  // deferred-voxel list of the split-sort rank kernels, lazily (num_voxels + 1)
+    unsigned char* d_workspace = nullptr;  // voxel tiles of the generic (cs > 128) kernels, lazily
+    size_t workspace_bytes = 0;
+    uint32_t* d_requests = nullptr;  // staging of host pair requests / their results, lazily
+    float* d_request_out = nullptr;
+    size_t request_capacity = 0;
+    uint32_t* d_minmax = nullptr;
+    bool minmax_valid = false;
+    float min_v = 0.f, max_v = 0.f;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::string last_kernel;
+    // host-output evaluations (crf_compute): the grid in up to kMaxHostChunks voxel ranges, one member-pointer table per
+    // range, so that the D2H copy of a finished range overlaps the kernels of the following ones
+    const float** d_chunk_tables = nullptr;  // host_chunks x cs pointers
+    int host_chunks = 0;                     // 0: tables not built for the current members
+    size_t chunk_voxels = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t chunk_done[kMaxHostChunks] = {};
+    size_t alloc_voxels = 0;  // voxels of the whole local grid (num_voxels is narrowed while a chunk is being launched)
+};
+
+
+// api.cpp internals used by the device group (group.cpp)
+namespace crf {
+// One evaluation straight into a caller-owned HOST buffer of the local grid: reference-side preparation once, then the
+// per-voxel kernel range by range with the D2H copies overlapped.  device_reference_values: device pointer to cs floats
+// or null (then params->reference_values / the reference point are used).
+int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out);
+// referenceValues[c] = (secondary ? secondary members : members)[c][IDXS(x,y,z)] into a device buffer, stream-ordered
+int gather_reference_to(crf_context* c, bool secondary, int x, int y, int z, float* device_out, hipStream_t s);
+}  // namespace crf

@@ -7,6 +7,14 @@
 
 namespace crf {
 
+// int(t) the way the reference's x86-64 build evaluates a bin index before clamping it to [0, numBins - 1]
+// (MutualInformation.cpp:66-67): cvttsd2si yields INT_MIN for NaN and for every t outside the int range -- so a POSITIVE
+// overflow (t >= 2^31: caller-supplied extrema far narrower than the data, or +inf data) lands in bin 0, where the
+// GPU's saturating conversion would give INT_MAX and bin numBins - 1.  Negative overflow and NaN saturate to values
+// that clamp to bin 0 either way, so one compare suffices.
+__device__ __forceinline__ int bin_index_x86(double t) { return t < 2147483648.0 ? int(t) : 0; }
+
+
 // Streaming member loads through buffer descriptors.  Member base pointers come out of a pointer table, so plain
 // loads are flat/global loads with a 64-bit VGPR address each (two VGPRs + a 64-bit VALU add per load in flight).  A
 // raw buffer load takes the wave-uniform base in a 128-bit SGPR descriptor and ONE shared 32-bit VGPR byte offset, and

@@ -92,6 +92,10 @@ struct KraskovArgs {
     int k;
     int estimator;  // 1 or 2
     bool to_cc;
+    // psi(k) for KSG-1, psi(k) - 1/k for KSG-2 (MutualInformation.cpp:438,503), evaluated on the host: k may exceed the
+    // member count (the reference accepts any k >= 1; its kd-tree just returns at most cs points), the device psi
+    // table ends at cs
+    double c_term;
 };
 hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                              const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out, hipStream_t s,
@@ -102,8 +106,8 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
                                     hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);
 
 hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
-                                       size_t num_voxels, int k, bool to_cc, const double* d_tables, float* d_out,
-                                       hipStream_t s);
+                                       size_t num_voxels, int k, double c_term, bool to_cc, const double* d_tables,
+                                       float* d_out, hipStream_t s);
 
 // ---- kernels_generic.hip: any member count (O(cs^2) counting algorithms, runtime loops) ------------------
 struct GenericArgs {
@@ -111,6 +115,7 @@ struct GenericArgs {
     int num_bins;
     float min_ref, max_ref, min_query, max_query;
     int k, estimator;
+    double kraskov_c;  // KraskovArgs::c_term
 };
 // workspace: generic_workspace_bytes(cs, num_voxels) bytes of device memory (per-block voxel tiles)
 size_t generic_workspace_bytes(int cs, size_t num_voxels);
@@ -138,6 +143,7 @@ struct PairArgs {
     int measure, num_bins, k, use_abs;
     int fixed_ranges;  // binned MI: 0 = normalise with the pair's own extrema (HEBChart), 1 = with the ranges below
     float min_ref, max_ref, min_query, max_query;
+    double kraskov_c;  // psi(k) (pair requests are KSG-1), host-evaluated like KraskovArgs::c_term
 };
 size_t pair_workspace_bytes(int cs, size_t num_requests);
 hipError_t launch_pair_requests(const float* const* d_members_i, const float* const* d_members_j, int cs, int xs, int ys,

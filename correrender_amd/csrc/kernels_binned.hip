@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const fl
         if (e < cs) {
             const float r01 = (load_ref(src, members, e) - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
             if (r01 == r01) {
-                int t = int(double(r01) * double(nb));
+                int t = bin_index_x86(double(r01) * double(nb));
                 b = t < 0 ? 0 : (t > nb - 1 ? nb - 1 : t);
             } else {
                 atomicAnd(&all_valid, 0);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
             const float q01 = (y[i] - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
             const int b0 = prep[e];                      // pads: kInvalidBin (binned_prep_kernel)
             const bool valid = member && (q01 == q01) && b0 != kInvalidBin;
-            int b1 = int(double(q01) * nbd);
+            int b1 = bin_index_x86(double(q01) * nbd);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
             a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
             total += valid ? 1 : 0;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void binned_hist_prep_kernel(RefSource src, co
         const float r01 = (load_ref(src, members, e) - min_ref) / (max_ref - min_ref);  // CorrelationCalculator.cpp:830-832
         int b = kInvalidBin;
         if (r01 == r01) {
-            const int t = int(double(r01) * double(nb));
+            const int t = bin_index_x86(double(r01) * double(nb));
             b = t < 0 ? 0 : (t > nb - 1 ? nb - 1 : t);
         } else {
             atomicAnd(&all_valid, 0);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void binned_hist_prep_kernel(RefSource src, co
 __device__ __forceinline__ int binned_query_bin(float y, float min_q, float range_q, double nbd, int nb, bool& valid) {
     const float q01 = (y - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
     valid = q01 == q01;
-    int b1 = int(double(q01) * nbd);
+    int b1 = bin_index_x86(double(q01) * nbd);
     return b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
 }
 

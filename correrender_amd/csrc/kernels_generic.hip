@@ -184,7 +184,7 @@ __device__ __forceinline__ int count_less_generic(const double* tab, int n, int 
 // Kraskov KSG-1 / KSG-2, any k: selection of the k-th neighbour distance by repeated minimum passes.
 __device__ float kraskov_voxel(const float* vals, const double* __restrict__ px, const double* __restrict__ spx,
                                const double* __restrict__ nq, const double* __restrict__ psi, int cs, int k,
-                               int estimator) {
+                               int estimator, double c_term) {
     const int kk = k < cs - 1 ? k : cs - 1;
     int top = 1;
     while (top * 2 <= cs) top *= 2;
@@ -246,9 +246,7 @@ __device__ float kraskov_voxel(const float* vals, const double* __restrict__ px,
         sum_x += factor * psi[cx];
         sum_y += factor * psi[cy];
     }
-    double c = psi[k <= cs ? k : cs];
-    if (estimator != 1) c -= 1.0 / double(k);
-    const double mi = -sum_x - sum_y + c + psi[cs];
+    const double mi = -sum_x - sum_y + c_term + psi[cs];
     const float res = float(mi);
     return (res < 0.0f) ? 0.0f : res;
 }
@@ -482,7 +480,7 @@ __global__ __launch_bounds__(64) void direct_symmetric_kernel(const float* const
                 is_nan |= xv != xv || yv != yv;
                 const float x01 = (xv - ba.min_x) / range_x, y01 = (yv - ba.min_y) / range_y;
                 const bool valid = (x01 == x01) && (y01 == y01);
-                int b0 = int(double(x01) * nbd), b1 = int(double(y01) * nbd);
+                int b0 = bin_index_x86(double(x01) * nbd), b1 = bin_index_x86(double(y01) * nbd);
                 b0 = b0 < 0 ? 0 : (b0 > ba.num_bins - 1 ? ba.num_bins - 1 : b0);
                 b1 = b1 < 0 ? 0 : (b1 > ba.num_bins - 1 ? ba.num_bins - 1 : b1);
                 codes[size_t(e) * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
@@ -633,7 +631,7 @@ __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restr
                 const float q01 = (y - a.min_query) / range_q;
                 const int b0 = prep_i[e];
                 const bool valid = (q01 == q01) && b0 != 0xFFFF;
-                int b1 = int(double(q01) * double(a.num_bins));
+                int b1 = bin_index_x86(double(q01) * double(a.num_bins));
                 b1 = b1 < 0 ? 0 : (b1 > a.num_bins - 1 ? a.num_bins - 1 : b1);
                 aux[e * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
                 total += valid ? 1 : 0;
@@ -652,7 +650,8 @@ __global__ __launch_bounds__(64) void generic_kernel(const float* const* __restr
             }
             default: {
                 const double* prep_d = static_cast<const double*>(prep);
-                res = kraskov_voxel(vals, prep_d, prep_d + cs, tables + 3 * cs + 2, tables, cs, a.k, a.estimator);
+                res = kraskov_voxel(vals, prep_d, prep_d + cs, tables + 3 * cs + 2, tables, cs, a.k, a.estimator,
+                                    a.kraskov_c);
                 if (a.measure == 6) res = mi_to_cc_generic(res);
                 break;
             }
@@ -779,7 +778,8 @@ __device__ float kendall_pair(const float* x, const float* y, int cs) {
 }
 
 __device__ float kraskov_pair(const float* x, const float* y, const double* __restrict__ nr,
-                              const double* __restrict__ nq, const double* __restrict__ psi, int cs, int k) {
+                              const double* __restrict__ nq, const double* __restrict__ psi, int cs, int k,
+                              double c_term) {
     const int kk = k < cs - 1 ? k : cs - 1;
     const double factor = 1.0 / double(cs);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -817,7 +817,7 @@ __device__ float kraskov_pair(const float* x, const float* y, const double* __re
         sum_x += factor * psi[cx > 1 ? cx : 1];
         sum_y += factor * psi[cy > 1 ? cy : 1];
     }
-    const double mi = -sum_x - sum_y + psi[k <= cs ? k : cs] + psi[cs];
+    const double mi = -sum_x - sum_y + c_term + psi[cs];
     const float res = float(mi);
     return (res < 0.0f) ? 0.0f : res;
 }
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __
                 for (int e = 0; e < cs; e++) {
                     const float x01 = (x[e * 64] - mnx) / range_x, y01 = (y[e * 64] - mny) / range_y;
                     const bool valid = (x01 == x01) && (y01 == y01);
-                    int b0 = int(double(x01) * double(num_bins)), b1 = int(double(y01) * double(num_bins));
+                    int b0 = bin_index_x86(double(x01) * double(num_bins)), b1 = bin_index_x86(double(y01) * double(num_bins));
                     b0 = b0 < 0 ? 0 : (b0 > num_bins - 1 ? num_bins - 1 : b0);
                     b1 = b1 < 0 ? 0 : (b1 > num_bins - 1 ? num_bins - 1 : b1);
                     ax[e * 64] = valid ? uint16_t((b1 << 8) | b0) : uint16_t(0xFFFF);
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(64) void pair_request_kernel(const float* const* __
                 break;
             }
             default:
-                res = kraskov_pair(x, y, tables + 2 * (cs + 1), tables + 3 * cs + 2, tables, cs, k);
+                res = kraskov_pair(x, y, tables + 2 * (cs + 1), tables + 3 * cs + 2, tables, cs, k, a.kraskov_c);
                 if (measure == 6) res = mi_to_cc_generic(res);
                 break;
         }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
                                                         const double* __restrict__ table_psi,
                                                         const double* __restrict__ noise_query,
                                                         float* __restrict__ out, size_t num_voxels, int cs, int k,
-                                                        int estimator, int to_cc) {
+                                                        int estimator, int to_cc, double c_term) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_px = reinterpret_cast<double*>(smem);  // member order
     double* s_spx = s_px + cs;                       // ascending
@@ -250,10 +250,8 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
             }
         }
     }
-    double c = s_psi[k <= cs ? k : cs];
-    if (estimator != 1) c -= 1.0 / double(k);
     const double d = s_psi[cs];
-    const double mi = -sum_x - sum_y + c + d;
+    const double mi = -sum_x - sum_y + c_term + d;
     float res = float(mi);
     res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
     if (to_cc) res = mi_to_cc(res);
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                                                             const double* __restrict__ table_psi,
                                                             const double* __restrict__ noise_query,
                                                             float* __restrict__ out, size_t num_voxels, int cs, int k,
-                                                            int estimator, int to_cc) {
+                                                            int estimator, int to_cc, double c_term) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_px = reinterpret_cast<double*>(smem);  // member order
     double* s_spx = s_px + cs;                       // ascending
@@ -433,9 +431,7 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                 }
             }
         }
-        double c = table_psi[k <= cs ? k : cs];
-        if (estimator != 1) c -= 1.0 / double(k);
-        const double mi = -sum_x - sum_y + c + table_psi[cs];
+        const double mi = -sum_x - sum_y + c_term + table_psi[cs];
         float res = float(mi);
         res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
         if (to_cc) res = mi_to_cc(res);
@@ -470,7 +466,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
 #define CRF_LAUNCH_DIRECT(K, TI)                                                                                    \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, prep, psi, \
-                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
+                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
     if (kk <= 4) {
         CRF_LAUNCH_DIRECT(4, 8);
     } else if (kk <= 8) {
@@ -492,8 +488,8 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
 
 // symmetric field mode: X = d_members_x (reference field), Y = d_members_y (query field); KSG-1
 hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
-                                       size_t num_voxels, int k, bool to_cc, const double* d_tables, float* d_out,
-                                       hipStream_t s) {
+                                       size_t num_voxels, int k, double c_term, bool to_cc, const double* d_tables,
+                                       float* d_out, hipStream_t s) {
     if (cs == 1) return launch_fill(d_out, num_voxels, 1.0f, s);
     const int kk = k < cs - 1 ? k : cs - 1;
     const size_t lds = size_t(3 * cs) * sizeof(double);
@@ -506,7 +502,7 @@ hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const fl
     const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
 #define CRF_LAUNCH_SYM(K, TI)                                                                                        \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, true>), dim3(blocks), dim3(256), lds, s, d_members_y, d_members_x, \
-                       noise_ref, psi, noise_query, d_out, num_voxels, cs, k, 1, int(to_cc))
+                       noise_ref, psi, noise_query, d_out, num_voxels, cs, k, 1, int(to_cc), c_term)
     if (kk <= 4) {
         CRF_LAUNCH_SYM(4, 8);
     } else if (kk <= 8) {
@@ -555,7 +551,7 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const bool wide = cs % 16 == 0 || cs % 16 > 8;
 #define CRF_LAUNCH_KRASKOV(K, TI)                                                                                     \
     hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
-                       d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc))
+                       d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
     switch (kk) {
         case 1: CRF_LAUNCH_KRASKOV(1, 8); break;
         // 16 points per sweep where the member count fills the last tile well: 253 VGPRs still give the 2 waves per SIMD

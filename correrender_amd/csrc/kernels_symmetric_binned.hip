@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
             const bool member = is_member(e);
             is_nan |= member && ((x[e] != x[e]) || (y[e] != y[e]));
             const float x01 = (x[e] - mn) / range, y01 = (y[e] - mn) / range;
-            int b0 = int(double(x01) * nbd), b1 = int(double(y01) * nbd);
+            int b0 = bin_index_x86(double(x01) * nbd), b1 = bin_index_x86(double(y01) * nbd);
             b0 = b0 < 0 ? 0 : (b0 > nb - 1 ? nb - 1 : b0);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
             const bool valid = member && (x01 == x01) && (y01 == y01);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
             const bool member = is_member(e);
             is_nan |= member && (x[e] != x[e]);
             const float x01 = (x[e] - ba.min_x) / range_x;  // CorrelationCalculator.cpp:1061-1062
-            int b0 = int(double(x01) * nbd);
+            int b0 = bin_index_x86(double(x01) * nbd);
             b0 = b0 < 0 ? 0 : (b0 > nb - 1 ? nb - 1 : b0);
             a[e] = (member && x01 == x01) ? uint32_t(b0) : kPadCode;
         }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
             const bool member = is_member(e);
             is_nan |= member && (y[e] != y[e]);
             const float y01 = (y[e] - ba.min_y) / range_y;
-            int b1 = int(double(y01) * nbd);
+            int b1 = bin_index_x86(double(y01) * nbd);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
             const bool valid = member && (y01 == y01) && a[e] != kPadCode;
             a[e] = valid ? (uint32_t(b1) << 8) | a[e] : kPadCode;

@@ -33,7 +33,7 @@ def slab_owner(zs: int, world: int, z: int) -> Tuple[int, int]:
     split = rem * (base + 1)
     if z < split:
         r = z // (base + 1)
-    else:
+    else:  # z >= split implies base >= 1 (base == 0 means split == zs > z)
         r = rem + (z - split) // base
     z0, _ = slab_bounds(zs, world, r)
     return r, z - z0
@@ -62,9 +62,11 @@ class ShardedCorrField:
         self._collectives = world > 1 or (always_exchange and dist.is_available() and dist.is_initialized())
         self.xs, self.ys, self.zs = grid
         self.cs = cs
+        # world and zs are the same on every rank, so this raises on ALL ranks together -- before any collective, never
+        # on the empty ranks alone while the others go on to wait in an all-reduce
+        if world > self.zs:
+            raise ValueError(f"{world} ranks cannot share a grid of {self.zs} z-slices: every rank needs a slice")
         self.z_begin, self.z_count = slab_bounds(self.zs, world, rank)
-        if self.z_count <= 0:
-            raise ValueError(f"rank {rank} of {world} owns no slice of a grid with zs={self.zs}")
         self.device = device if device is not None else torch.device("cpu")
         engine.set_grid(self.xs, self.ys, self.z_count, cs)
         # Reference-vector buffers, used round-robin.  prefetch() fills the next one on a side (communication) stream

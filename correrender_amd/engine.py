@@ -202,8 +202,9 @@ class CorrField:
 
     def compute(self, measure, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
                 minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False,
-                absolute_value=False) -> np.ndarray:
+                absolute_value=False, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Synchronous evaluation to a host array of shape (zs, ys, xs) -- calculateCpu(t, e, buffer).
+        out: caller-owned C-contiguous float32 array of xs*ys*zs elements to write into (default: a new array).
         symmetric: SEPARATE_SYMMETRIC field mode (primary vs secondary members at every voxel);
         reference_from_secondary: SEPARATE field mode (reference vector = secondary members at `ref`);
         absolute_value: opt-in |.| of the field (the reference's CPU path never applies it)."""
@@ -212,7 +213,10 @@ class CorrField:
         p, keep = self._params(measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
                                reference_values, flags)
         xs, ys, zs = self.grid
-        out = np.empty((zs, ys, xs), dtype=np.float32)
+        if out is None:
+            out = np.empty((zs, ys, xs), dtype=np.float32)
+        elif out.dtype != np.float32 or out.size != self.num_voxels or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 array of xs*ys*zs elements")
         self._check(self._lib.crf_compute(self._ctx, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))))
         del keep
         return out

@@ -16,6 +16,11 @@
  *     maps a non-zero status + crf_last_error() onto that).
  *   - single caller thread per context (the reference calls calculators from the render thread only,
  *     VolumeData.cpp:1225,1469-1472); no re-entrancy.
+ *   - the *_device entry points are asynchronous on the stream they are given, but a context owns ONE set of scratch
+ *     buffers (reference vector, reference-side tables, deferred-voxel list, workspace): at most one evaluation per
+ *     context may be in flight at a time unless consecutive calls are ordered on the same stream (or by events).  The
+ *     only state meant for overlap across streams are the prepared slots of crf_prepare_device.  crf_set_grid and any
+ *     call that has to grow a scratch buffer synchronise the device first.
  *   - volumes are fp32, x fastest: voxel (x,y,z) at z*xs*ys + y*xs + x  (IDXS, src/Loaders/DataSet.hpp:37);
  *     the ensemble is member-major SoA: one contiguous volume per member
  *     (std::vector<const float*> fields, CorrelationCalculator.cpp:791-800).

@@ -193,8 +193,11 @@ float mi_binned_f64(const float* x01, const float* y01, int numBins, int n, Binn
     for (int e = 0; e < n; e++) {
         const double vx = x01[e], vy = y01[e];
         if (!std::isnan(vx) && !std::isnan(vy)) {
-            const int bx = std::clamp(int(vx * double(numBins)), 0, numBins - 1);
-            const int by = std::clamp(int(vy * double(numBins)), 0, numBins - 1);
+            // int(t) as the reference's x86-64 build converts it (cvttsd2si: INT_MIN outside the int range) -- spelled
+            // out instead of relying on undefined behaviour; only reachable with extrema far narrower than the data
+            auto to_int = [](double t) { return (t > -2147483649.0 && t < 2147483648.0) ? int(t) : std::numeric_limits<int>::min(); };
+            const int bx = std::clamp(to_int(vx * double(numBins)), 0, numBins - 1);
+            const int by = std::clamp(to_int(vy * double(numBins)), 0, numBins - 1);
             s.hxy[size_t(bx) * nb + size_t(by)] += 1.0;
         }
     }

@@ -34,6 +34,16 @@ def test_slab_arithmetic():
         slab_owner(8, 2, 8)
 
 
+def test_more_ranks_than_slices_is_refused_on_every_rank():
+    """world > zs: every rank raises before any collective (an empty rank raising alone would leave the others
+    waiting in an all-reduce).  slab_owner stays well defined for world > zs."""
+    from fake_engine import OracleEngine
+    for rank in range(4):
+        with pytest.raises(ValueError, match="cannot share"):
+            ShardedCorrField(OracleEngine(), (4, 4, 3), 8, rank=rank, world=4)
+    assert [slab_owner(3, 4, z) for z in range(3)] == [(0, 0), (1, 0), (2, 0)]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

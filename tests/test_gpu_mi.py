@@ -104,6 +104,38 @@ def test_kraskov_ksg1(engine, oracle, cs, k):
     assert (got >= 0).all()        # clamped at 0 (MutualInformation.cpp:443)
 
 
+@pytest.mark.parametrize("cs,k,estimator", [(8, 12, 1), (8, 12, 2), (16, 20, 1), (5, 20, 1), (3, 7, 2), (40, 41, 1),
+                                             (140, 150, 1)])
+def test_kraskov_k_beyond_member_count(engine, oracle, cs, k, estimator):
+    """k > cs: the reference accepts it (its UI allows kMax = max(ceil(7 cs / 100), 20), CorrelationCalculator.cpp:592-598):
+    the (k+1)-nearest-neighbour query returns all cs points, psi(k) itself enters the estimate
+    (MutualInformation.cpp:430-438)."""
+    ens = synth.normal_ensemble(16, 8, 3, cs, seed=900 + cs)
+    _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
+           f"KSG-{estimator} cs={cs} k={k} (k > cs)", ref_xyz=(2, 2, 1), k=k, kraskov_estimator_index=estimator,
+           min_identical=0.99)
+
+
+@pytest.mark.parametrize("cs", [12, 64, 100, 140])
+def test_binned_positive_overflow_of_the_bin_index(engine, oracle, cs):
+    """Caller-supplied extrema much narrower than the data (crf_params min/max are the caller's) and +inf data with a
+    finite range: value * numBins reaches 2^31 and the reference's int() -- cvttsd2si on x86-64 -- yields INT_MIN,
+    i.e. bin 0 after the clamp (MutualInformation.cpp:66-67), not the last bin."""
+    rng = np.random.default_rng(40 + cs)
+    ens = (rng.standard_normal((cs, 2, 6, 16)) * 100.0).astype(np.float32)
+    ens[1, 0, 2, 3] = np.inf
+    ens[2, 1, 4, 5] = -np.inf
+    engine.set_grid(16, 6, 2, cs)
+    engine.upload_members(ens)
+    narrow = (0.0, 1e-8)             # (v - 0) / 1e-8 * 80 > 2^31 for |v| > 0.27
+    for ref in [(0, 0, 0), (3, 2, 0)]:
+        got = engine.compute(Measure.MUTUAL_INFORMATION_BINNED, ref, num_bins=80, minmax_ref=narrow,
+                             minmax_query=narrow).reshape(-1)
+        want = oracle.field(oracle_lib.MI_BINNED, ens, ens[:, ref[2], ref[1], ref[0]].copy(), num_bins=80,
+                            minmax_ref=narrow)
+        assert_close(got, want, f"binned bin-index overflow cs={cs} ref={ref}")
+
+
 @pytest.mark.parametrize("cs,k", [(16, 2), (64, 3), (100, 5), (64, 12), (100, 40), (160, 70)])
 def test_kraskov_ksg2(engine, oracle, cs, k):
     ens = synth.normal_ensemble(16, 8, 6, cs, seed=400 + cs)
