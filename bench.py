@@ -445,7 +445,20 @@ def measure_host_boundary(args, eng, measure, pts, kwargs, n_total):
         t_fresh.append(time.perf_counter() - t0)
         del fresh
     med = lambda v: sorted(v)[len(v) // 2]
+    # the floor of this boundary on this box: one plain DMA of the same bytes into pinned host memory
+    import torch
+    dev = torch.empty(n_total, dtype=torch.float32, device="cuda")
+    pinned = torch.empty(n_total, dtype=torch.float32).pin_memory()
+    t_dma = []
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pinned.copy_(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        t_dma.append(time.perf_counter() - t0)
+    t_dma = t_dma[2:]
     return {"entry": "crf_compute (host output buffer)", "bytes_d2h": n_total * 4,
+            "pcie_d2h_pinned_floor_ms": round(med(t_dma) * 1e3, 3),
             "resident_ms": round(med(t_res) * 1e3, 3), "resident_value": round(n_total / med(t_res) / 1e6, 1),
             "fresh_ms": round(med(t_fresh) * 1e3, 3), "fresh_value": round(n_total / med(t_fresh) / 1e6, 1),
             "unit": "Mvoxel-corr/s", "runs": reps}

@@ -7,7 +7,7 @@ kernels behind the C ABI of ``include/corrfield.h``); this package is the thin P
 by the tests, the benchmark and the multi-GPU (one process per GPU) driver.  There is no CPU fallback.
 """
 from ._lib import CorrFieldError, load_library, library_path  # noqa: F401
-from .engine import CorrField, Measure, MEASURE_IDS, default_kraskov_k  # noqa: F401
+from .engine import CorrField, CorrFieldGroup, Measure, MEASURE_IDS, default_kraskov_k  # noqa: F401
 
-__all__ = ["CorrField", "Measure", "MEASURE_IDS", "CorrFieldError", "load_library", "library_path",
+__all__ = ["CorrField", "CorrFieldGroup", "Measure", "MEASURE_IDS", "CorrFieldError", "load_library", "library_path",
            "default_kraskov_k"]

@@ -81,6 +81,22 @@ SYMBOLS = {
     "crf_last_kernel_name": (C.c_char_p, [_VOIDP]),
     "crf_synth_box_member": (C.c_int, [_VOIDP, _VOIDP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_uint64, _VOIDP]),
+    # several devices behind one caller thread
+    "crf_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_VOIDP)]),
+    "crf_group_destroy": (None, [_VOIDP]),
+    "crf_group_last_error": (C.c_char_p, [_VOIDP]),
+    "crf_group_size": (C.c_int, [_VOIDP]),
+    "crf_group_exchange": (C.c_char_p, [_VOIDP]),
+    "crf_group_context": (_VOIDP, [_VOIDP, C.c_int]),
+    "crf_group_set_grid": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crf_group_slab": (C.c_int, [_VOIDP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crf_group_upload_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_group_upload_secondary_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
+    "crf_group_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crf_group_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crf_group_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
+    "crf_group_set_profiling": (C.c_int, [_VOIDP, C.c_int]),
+    "crf_group_take_kernel_time": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 

@@ -10,7 +10,7 @@
 #include "../../include/corrfield.h"
 #include "crf_internal.h"
 
-constexpr int kMaxHostChunks = 8;  // z-chunks of a host-output evaluation (kernel of chunk i+1 under the D2H of chunk i)
+constexpr int kMaxHostChunks = 16;  // z-chunks of a host-output evaluation (kernel of chunk i+1 under the D2H of chunk i)
 
 struct crf_context {
     int device = -1;
@@ -56,7 +56,9 @@ struct crf_context {
     int host_chunks = 0;                     // 0: tables not built for the current members
     size_t chunk_voxels = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t chunk_done[kMaxHostChunks] = {};
+    hipEvent_t chunk_done[kMaxHostChunks] = {};    // range evaluated (compute stream)
+    hipEvent_t chunk_copied[kMaxHostChunks] = {};  // range landed in the staging buffer (copy stream)
+    float* h_staging = nullptr;                    // pinned, alloc_voxels floats, lazily
     size_t alloc_voxels = 0;  // voxels of the whole local grid (num_voxels is narrowed while a chunk is being launched)
 };
 

@@ -320,7 +320,7 @@ int crf_group_set_grid(crf_group* g, int xs, int ys, int zs, int cs) {
     g->zs = zs;
     g->cs = cs;
     for (int r = 0; r < g->n; r++) slab(zs, g->n, r, &g->z_begin[size_t(r)], &g->z_count[size_t(r)]);
-    const int status = g->workers->run([&](int r) {
+    const int status = g->workers->run([&](int r) -> int {
         if (int rc = crf_set_grid(g->ctx[size_t(r)], xs, ys, g->z_count[size_t(r)], cs)) return rc;
         return hipMalloc(reinterpret_cast<void**>(&g->d_refvec[size_t(r)]), sizeof(float) * size_t(cs)) == hipSuccess
                    ? CRF_OK
@@ -342,7 +342,7 @@ static int upload_slabs(crf_group* g, const float* const* host_members, bool sec
     for (int c = 0; c < g->cs; c++)
         if (!host_members[c]) return gfail(g, CRF_ERR_ARGUMENT, fmt("member %d is a null pointer", c));
     const size_t slice = size_t(g->xs) * size_t(g->ys);
-    const int status = g->workers->run([&](int r) {
+    const int status = g->workers->run([&](int r) -> int {
         std::vector<const float*> slabs(size_t(g->cs));
         for (int c = 0; c < g->cs; c++) slabs[size_t(c)] = host_members[c] + slice * size_t(g->z_begin[size_t(r)]);
         return secondary ? crf_upload_secondary_members(g->ctx[size_t(r)], slabs.data())
@@ -360,7 +360,7 @@ int crf_group_upload_secondary_members(crf_group* g, const float* const* host_me
 static int group_minmax(crf_group* g, bool secondary, float* out_min, float* out_max) {
     if (!g || !out_min || !out_max) return gfail(g, CRF_ERR_ARGUMENT, "null argument");
     std::vector<float> mn(size_t(g->n)), mx(size_t(g->n));
-    const int status = g->workers->run([&](int r) {
+    const int status = g->workers->run([&](int r) -> int {
         return secondary ? crf_secondary_member_minmax(g->ctx[size_t(r)], &mn[size_t(r)], &mx[size_t(r)])
                          : crf_member_minmax(g->ctx[size_t(r)], &mn[size_t(r)], &mx[size_t(r)]);
     });

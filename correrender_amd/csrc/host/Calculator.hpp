@@ -65,6 +65,28 @@ private:
     std::map<std::string, std::string> settings;
 };
 
+// One persisted settings key of a calculator: how it is read from a SettingsMap into the object (returns true when the
+// key was present and applied -- the calculator then marks itself dirty) and how it is written back.  The calculators
+// keep one static table of these per class; setSettings / getSettings walk the table in order (keys that decide how
+// later ones are interpreted -- e.g. the field mode before the field indices -- simply come first).
+template <class Owner>
+struct SettingBinding {
+    const char* key;
+    bool (*load)(Owner&, const SettingsMap&);
+    void (*store)(const Owner&, SettingsMap&);  // null: not written back
+};
+template <class Owner, size_t N>
+bool loadSettings(Owner& owner, const SettingBinding<Owner> (&table)[N], const SettingsMap& settings) {
+    bool any = false;
+    for (const auto& b : table) any |= b.load(owner, settings);
+    return any;
+}
+template <class Owner, size_t N>
+void storeSettings(const Owner& owner, const SettingBinding<Owner> (&table)[N], SettingsMap& settings) {
+    for (const auto& b : table)
+        if (b.store) b.store(owner, settings);
+}
+
 class VolumeData;
 
 // The reference reports errors through sgl::Logfile::get()->throwError (logs, then throws); here: an exception.

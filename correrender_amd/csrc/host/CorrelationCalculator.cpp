@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <sstream>
 
 namespace crfhost {
 
@@ -65,75 +66,97 @@ void ICorrelationCalculator::setReferencePoint(const std::array<int, 3>& referen
     }
 }
 
+// Settings keys of ICorrelationCalculator (the reference's keys and value spellings, CorrelationCalculator.cpp:397-565):
+// the field mode comes first because it decides which field-index keys apply.
+const SettingBinding<ICorrelationCalculator> ICorrelationCalculator::kSettings[] = {
+    {"correlation_field_mode",
+     [](ICorrelationCalculator& c, const SettingsMap& m) {
+         std::string name;
+         if (!m.getValueOpt("correlation_field_mode", name)) return false;
+         const auto* end = CORRELATION_FIELD_MODE_NAMES + 3;
+         const auto* hit = std::find(CORRELATION_FIELD_MODE_NAMES, end, name);
+         if (hit != end) c.correlationFieldMode = CorrelationFieldMode(hit - CORRELATION_FIELD_MODE_NAMES);
+         return true;
+     },
+     [](const ICorrelationCalculator& c, SettingsMap& m) {
+         m.addKeyValue("correlation_field_mode", CORRELATION_FIELD_MODE_NAMES[int(c.correlationFieldMode)]);
+     }},
+    {"scalar_field_idx_ref",
+     [](ICorrelationCalculator& c, const SettingsMap& m) {
+         if (c.correlationFieldMode == CorrelationFieldMode::SINGLE || !m.getValueOpt("scalar_field_idx_ref", c.fieldIndex2Gui))
+             return false;
+         c.fieldIndex2 = c.fieldIndex2Gui;
+         return true;
+     },
+     [](const ICorrelationCalculator& c, SettingsMap& m) {
+         if (c.correlationFieldMode != CorrelationFieldMode::SINGLE) m.addKeyValue("scalar_field_idx_ref", c.fieldIndex2Gui);
+     }},
+    {"scalar_field_idx_query",
+     [](ICorrelationCalculator& c, const SettingsMap& m) {
+         if (c.correlationFieldMode == CorrelationFieldMode::SINGLE || !m.getValueOpt("scalar_field_idx_query", c.fieldIndexGui))
+             return false;
+         c.fieldIndex = c.fieldIndexGui;
+         return true;
+     },
+     [](const ICorrelationCalculator& c, SettingsMap& m) {
+         if (c.correlationFieldMode != CorrelationFieldMode::SINGLE) m.addKeyValue("scalar_field_idx_query", c.fieldIndexGui);
+     }},
+    {"scalar_field_idx",
+     [](ICorrelationCalculator& c, const SettingsMap& m) {
+         if (c.correlationFieldMode != CorrelationFieldMode::SINGLE || !m.getValueOpt("scalar_field_idx", c.fieldIndexGui))
+             return false;
+         c.fieldIndex = c.fieldIndexGui;
+         return true;
+     },
+     [](const ICorrelationCalculator& c, SettingsMap& m) {
+         if (c.correlationFieldMode == CorrelationFieldMode::SINGLE) m.addKeyValue("scalar_field_idx", c.fieldIndexGui);
+     }},
+    {"correlation_mode",
+     [](ICorrelationCalculator& c, const SettingsMap& m) {
+         std::string name;
+         if (!m.getValueOpt("correlation_mode", name)) return false;
+         c.isEnsembleMode = name == CORRELATION_MODE_NAMES[0];
+         c.onCorrelationMemberCountChanged();
+         return true;
+     },
+     [](const ICorrelationCalculator& c, SettingsMap& m) {
+         m.addKeyValue("correlation_mode", CORRELATION_MODE_NAMES[c.isEnsembleMode ? 0 : 1]);
+     }},
+    {"reference_point_x", [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("reference_point_x", c.referencePointIndex[0]); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("reference_point_x", c.referencePointIndex[0]); }},
+    {"reference_point_y", [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("reference_point_y", c.referencePointIndex[1]); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("reference_point_y", c.referencePointIndex[1]); }},
+    {"reference_point_z", [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("reference_point_z", c.referencePointIndex[2]); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("reference_point_z", c.referencePointIndex[2]); }},
+    // the only data mode of this backend; written for state files, never read
+    {"data_mode", [](ICorrelationCalculator&, const SettingsMap&) { return false; },
+     [](const ICorrelationCalculator&, SettingsMap& m) { m.addKeyValue("data_mode", "Buffer Array"); }},
+    {"use_buffer_tiling", [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("use_buffer_tiling", c.useBufferTiling); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("use_buffer_tiling", c.useBufferTiling); }},
+    {"use_time_lag_correlations",
+     [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("use_time_lag_correlations", c.useTimeLagCorrelations); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("use_time_lag_correlations", c.useTimeLagCorrelations); }},
+    {"time_lag_time_step_idx",
+     [](ICorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("time_lag_time_step_idx", c.timeLagTimeStepIdx); },
+     [](const ICorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("time_lag_time_step_idx", c.timeLagTimeStepIdx); }},
+};
+
 void ICorrelationCalculator::setSettings(const SettingsMap& settings) {
-    std::string correlationFieldModeString;
-    if (settings.getValueOpt("correlation_field_mode", correlationFieldModeString)) {
-        for (int i = 0; i < 3; i++) {
-            if (correlationFieldModeString == CORRELATION_FIELD_MODE_NAMES[i]) {
-                correlationFieldMode = CorrelationFieldMode(i);
-                break;
-            }
-        }
-        dirty = true;
-    }
-    if (correlationFieldMode != CorrelationFieldMode::SINGLE) {
-        if (settings.getValueOpt("scalar_field_idx_ref", fieldIndex2Gui)) {
-            fieldIndex2 = fieldIndex2Gui;
-            dirty = true;
-        }
-        if (settings.getValueOpt("scalar_field_idx_query", fieldIndexGui)) {
-            fieldIndex = fieldIndexGui;
-            dirty = true;
-        }
-    } else if (settings.getValueOpt("scalar_field_idx", fieldIndexGui)) {
-        fieldIndex = fieldIndexGui;
-        dirty = true;
-    }
-    std::string ensembleModeName;
-    if (settings.getValueOpt("correlation_mode", ensembleModeName)) {
-        isEnsembleMode = ensembleModeName == CORRELATION_MODE_NAMES[0];
-        onCorrelationMemberCountChanged();
-        dirty = true;
-    }
-    bool referencePointChanged = false;
-    referencePointChanged |= settings.getValueOpt("reference_point_x", referencePointIndex[0]);
-    referencePointChanged |= settings.getValueOpt("reference_point_y", referencePointIndex[1]);
-    referencePointChanged |= settings.getValueOpt("reference_point_z", referencePointIndex[2]);
-    if (referencePointChanged) dirty = true;
-    if (settings.getValueOpt("use_buffer_tiling", useBufferTiling)) dirty = true;
-    if (settings.getValueOpt("use_time_lag_correlations", useTimeLagCorrelations)) dirty = true;
-    if (settings.getValueOpt("time_lag_time_step_idx", timeLagTimeStepIdx)) dirty = true;
+    if (loadSettings(*this, kSettings, settings)) dirty = true;
 }
 
-void ICorrelationCalculator::getSettings(SettingsMap& settings) {
-    settings.addKeyValue("correlation_field_mode", CORRELATION_FIELD_MODE_NAMES[int(correlationFieldMode)]);
-    if (correlationFieldMode != CorrelationFieldMode::SINGLE) {
-        settings.addKeyValue("scalar_field_idx_ref", fieldIndex2Gui);
-        settings.addKeyValue("scalar_field_idx_query", fieldIndexGui);
-    } else {
-        settings.addKeyValue("scalar_field_idx", fieldIndexGui);
-    }
-    settings.addKeyValue("correlation_mode", CORRELATION_MODE_NAMES[isEnsembleMode ? 0 : 1]);
-    settings.addKeyValue("reference_point_x", referencePointIndex[0]);
-    settings.addKeyValue("reference_point_y", referencePointIndex[1]);
-    settings.addKeyValue("reference_point_z", referencePointIndex[2]);
-    settings.addKeyValue("data_mode", "Buffer Array");
-    settings.addKeyValue("use_buffer_tiling", useBufferTiling);
-    settings.addKeyValue("use_time_lag_correlations", useTimeLagCorrelations);
-    settings.addKeyValue("time_lag_time_step_idx", timeLagTimeStepIdx);
-}
+void ICorrelationCalculator::getSettings(SettingsMap& settings) { storeSettings(*this, kSettings, settings); }
 
 // ---------------------------------------------------------------------------------------------------------
 // CorrelationCalculator (CorrelationCalculator.cpp:569-779)
 // ---------------------------------------------------------------------------------------------------------
-CorrelationCalculator::CorrelationCalculator(int device) : device(device) {}
+CorrelationCalculator::CorrelationCalculator(int device) : device(device), devices{device} {}
 
-CorrelationCalculator::~CorrelationCalculator() {
-    if (ctx) crf_destroy(ctx);
-}
+CorrelationCalculator::~CorrelationCalculator() { releaseBackend(); }
 
 void CorrelationCalculator::throwBackendError(const char* where) {
-    throw CalculatorError(std::string("Error in CorrelationCalculator::") + where + ": " + crf_last_error(ctx));
+    throw CalculatorError(std::string("Error in CorrelationCalculator::") + where + ": " +
+                          (group ? crf_group_last_error(group) : crf_last_error(ctx)));
 }
 
 std::string CorrelationCalculator::getOutputFieldName() {
@@ -174,45 +197,90 @@ std::pair<float, float> CorrelationCalculator::getFixedRange() const {
     return {0.0f, 1.0f};
 }
 
+// Settings keys of CorrelationCalculator (CorrelationCalculator.cpp:706-779), plus "devices": this backend's own key,
+// a comma-separated list of HIP device ordinals -- more than one spreads the grid over a crf_group (z-slabs, one per
+// device); written back only when it is not the single default device, so reference state files round-trip unchanged.
+const SettingBinding<CorrelationCalculator> CorrelationCalculator::kSettings[] = {
+    {"correlation_measure_type",
+     [](CorrelationCalculator& c, const SettingsMap& m) {
+         std::string id;
+         if (!m.getValueOpt("correlation_measure_type", id)) return false;
+         const auto* end = CORRELATION_MEASURE_TYPE_IDS + 7;
+         const auto* hit = std::find_if(CORRELATION_MEASURE_TYPE_IDS, end, [&](const char* s) { return id == s; });
+         if (hit != end) c.correlationMeasureType = CorrelationMeasureType(hit - CORRELATION_MEASURE_TYPE_IDS);
+         c.hasNameChanged = true;
+         return true;
+     },
+     [](const CorrelationCalculator& c, SettingsMap& m) {
+         m.addKeyValue("correlation_measure_type", CORRELATION_MEASURE_TYPE_IDS[int(c.correlationMeasureType)]);
+     }},
+    // "CPU" | "Vulkan" | "CUDA"; anything else means the accelerator (CorrelationCalculator.cpp:721-747)
+    {"device",
+     [](CorrelationCalculator& c, const SettingsMap& m) {
+         std::string name;
+         if (!m.getValueOpt("device", name)) return false;
+         const bool before = c.useGpu;
+         c.useGpu = name != "CPU";
+         c.useCuda = name == "CUDA";
+         c.hasFilterDeviceChanged = before != c.useGpu;
+         return true;
+     },
+     [](const CorrelationCalculator& c, SettingsMap& m) {
+         m.addKeyValue("device", !c.useGpu ? "CPU" : (!c.useCuda ? "Vulkan" : "CUDA"));
+     }},
+    {"calculate_absolute_value",
+     [](CorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("calculate_absolute_value", c.calculateAbsoluteValue); },
+     [](const CorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("calculate_absolute_value", c.calculateAbsoluteValue); }},
+    {"mi_bins", [](CorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("mi_bins", c.numBins); },
+     [](const CorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("mi_bins", c.numBins); }},
+    {"kmi_neighbors", [](CorrelationCalculator& c, const SettingsMap& m) { return m.getValueOpt("kmi_neighbors", c.k); },
+     [](const CorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("kmi_neighbors", c.k); }},
+    {"kraskov_estimator_index",
+     [](CorrelationCalculator& c, const SettingsMap& m) {
+         if (!m.getValueOpt("kraskov_estimator_index", c.kraskovEstimatorIndex)) return false;
+         c.kraskovEstimatorIndex = std::clamp(c.kraskovEstimatorIndex, 1, 2);
+         return true;
+     },
+     [](const CorrelationCalculator& c, SettingsMap& m) { m.addKeyValue("kraskov_estimator_index", c.kraskovEstimatorIndex); }},
+    {"devices",
+     [](CorrelationCalculator& c, const SettingsMap& m) {
+         std::string list;
+         if (!m.getValueOpt("devices", list)) return false;
+         std::vector<int> ordinals;
+         std::istringstream is(list);
+         for (std::string item; std::getline(is, item, ',');)
+             if (!item.empty()) ordinals.push_back(std::stoi(item));
+         if (ordinals.empty()) ordinals.push_back(c.device);
+         if (ordinals != c.devices) {
+             c.devices = ordinals;
+             c.releaseBackend();  // the members have to be distributed again
+         }
+         return true;
+     },
+     [](const CorrelationCalculator& c, SettingsMap& m) {
+         if (c.devices.size() == 1 && c.devices[0] == c.device) return;
+         std::string list;
+         for (size_t i = 0; i < c.devices.size(); i++) list += (i ? "," : "") + std::to_string(c.devices[i]);
+         m.addKeyValue("devices", list);
+     }},
+};
+
 void CorrelationCalculator::setSettings(const SettingsMap& settings) {
     ICorrelationCalculator::setSettings(settings);
-    std::string correlationMeasureTypeName;
-    if (settings.getValueOpt("correlation_measure_type", correlationMeasureTypeName)) {
-        for (int i = 0; i < 7; i++) {
-            if (correlationMeasureTypeName == CORRELATION_MEASURE_TYPE_IDS[i]) {
-                correlationMeasureType = CorrelationMeasureType(i);
-                break;
-            }
-        }
-        hasNameChanged = true;
-        dirty = true;
-    }
-    std::string deviceName;
-    if (settings.getValueOpt("device", deviceName)) {
-        // "CPU" | "Vulkan" | "CUDA"; anything else falls back to the accelerator (CorrelationCalculator.cpp:721-747).
-        const bool useGpuOld = useGpu;
-        useGpu = deviceName != "CPU";
-        useCuda = deviceName == "CUDA";
-        hasFilterDeviceChanged = useGpuOld != useGpu;
-        dirty = true;
-    }
-    if (settings.getValueOpt("calculate_absolute_value", calculateAbsoluteValue)) dirty = true;
-    if (settings.getValueOpt("mi_bins", numBins)) dirty = true;
-    if (settings.getValueOpt("kmi_neighbors", k)) dirty = true;
-    if (settings.getValueOpt("kraskov_estimator_index", kraskovEstimatorIndex)) {
-        kraskovEstimatorIndex = std::clamp(kraskovEstimatorIndex, 1, 2);
-        dirty = true;
-    }
+    if (loadSettings(*this, kSettings, settings)) dirty = true;
 }
 
 void CorrelationCalculator::getSettings(SettingsMap& settings) {
     ICorrelationCalculator::getSettings(settings);
-    settings.addKeyValue("correlation_measure_type", CORRELATION_MEASURE_TYPE_IDS[int(correlationMeasureType)]);
-    settings.addKeyValue("device", !useGpu ? "CPU" : (!useCuda ? "Vulkan" : "CUDA"));
-    settings.addKeyValue("calculate_absolute_value", calculateAbsoluteValue);
-    settings.addKeyValue("mi_bins", numBins);
-    settings.addKeyValue("kmi_neighbors", k);
-    settings.addKeyValue("kraskov_estimator_index", kraskovEstimatorIndex);
+    storeSettings(*this, kSettings, settings);
+}
+
+void CorrelationCalculator::releaseBackend() {
+    if (ctx) crf_destroy(ctx);
+    if (group) crf_group_destroy(group);
+    ctx = nullptr;
+    group = nullptr;
+    residentGeneration = ~uint64_t(0);
 }
 
 // Keeps the cs member volumes resident in HBM across evaluations; re-uploads only when the member set changes
@@ -220,14 +288,22 @@ void CorrelationCalculator::getSettings(SettingsMap& settings) {
 void CorrelationCalculator::ensureMembersResident(int timeStepIdx, int ensembleIdx, int cs) {
     const std::string& fieldName = scalarFieldNames.at(size_t(fieldIndexGui));
     const int fixedIdx = isEnsembleMode ? timeStepIdx : ensembleIdx;  // the index that is NOT the member axis
-    if (ctx && residentGeneration == volumeData->getDataGeneration() && residentField == fieldName &&
+    if ((ctx || group) && residentGeneration == volumeData->getDataGeneration() && residentField == fieldName &&
         residentCs == cs && residentEnsembleMode == isEnsembleMode &&
         (isEnsembleMode ? residentT == fixedIdx : residentE == fixedIdx))
         return;
-    if (!ctx && crf_create(device, &ctx) != CRF_OK)
-        throw CalculatorError(std::string("Error in CorrelationCalculator::calculateCpu: ") + crf_last_error(nullptr));
-    if (crf_set_grid(ctx, volumeData->getGridSizeX(), volumeData->getGridSizeY(), volumeData->getGridSizeZ(), cs))
-        throwBackendError("calculateCpu");
+    // one device: a plain context; several ("devices" setting): a device group -- z-slabs, one worker per device
+    if (devices.size() > 1) {
+        if (!group && crf_group_create(devices.data(), int(devices.size()), &group) != CRF_OK)
+            throw CalculatorError(std::string("Error in CorrelationCalculator::calculateCpu: ") + crf_group_last_error(nullptr));
+        if (crf_group_set_grid(group, volumeData->getGridSizeX(), volumeData->getGridSizeY(), volumeData->getGridSizeZ(), cs))
+            throwBackendError("calculateCpu");
+    } else {
+        if (!ctx && crf_create(devices[0], &ctx) != CRF_OK)
+            throw CalculatorError(std::string("Error in CorrelationCalculator::calculateCpu: ") + crf_last_error(nullptr));
+        if (crf_set_grid(ctx, volumeData->getGridSizeX(), volumeData->getGridSizeY(), volumeData->getGridSizeZ(), cs))
+            throwBackendError("calculateCpu");
+    }
     std::vector<HostCacheEntry> fieldEntries;
     std::vector<const float*> fields;
     fieldEntries.reserve(size_t(cs));
@@ -237,7 +313,8 @@ void CorrelationCalculator::ensureMembersResident(int timeStepIdx, int ensembleI
         fieldEntries.push_back(fieldEntry);
         fields.push_back(fieldEntry->data<float>());
     }
-    if (crf_upload_members(ctx, fields.data())) throwBackendError("calculateCpu");
+    if (group ? crf_group_upload_members(group, fields.data()) : crf_upload_members(ctx, fields.data()))
+        throwBackendError("calculateCpu");
     residentGeneration = volumeData->getDataGeneration();
     residentField = fieldName;
     residentCs = cs;
@@ -256,7 +333,8 @@ void CorrelationCalculator::uploadSecondaryMembers(int timeStepIdx, int ensemble
         fieldEntries.push_back(getFieldEntryCpu(fieldName, fieldIdx, timeStepIdx, ensembleIdx));
         fields.push_back(fieldEntries.back()->data<float>());
     }
-    if (crf_upload_secondary_members(ctx, fields.data())) throwBackendError("calculateCpu");
+    if (group ? crf_group_upload_secondary_members(group, fields.data()) : crf_upload_secondary_members(ctx, fields.data()))
+        throwBackendError("calculateCpu");
 }
 
 void CorrelationCalculator::calculateCpu(int timeStepIdx, int ensembleIdx, float* buffer) {
@@ -326,11 +404,18 @@ void CorrelationCalculator::calculateCpu(int timeStepIdx, int ensembleIdx, float
         std::swap(params.max_ref, params.max_query);
     }
 
-    crf_set_profiling(ctx, 1);
-    if (crf_compute(ctx, &params, buffer)) throwBackendError("calculateCpu");
+    // kernel time of this evaluation: the sum over the voxel ranges of the host-output path (slowest device of a group)
     double ms = 0.0;
     int launches = 0;
-    lastKernelMs = (crf_take_kernel_time(ctx, &ms, &launches) == CRF_OK && launches > 0) ? ms / launches : -1.0;
+    if (group) {
+        crf_group_set_profiling(group, 1);
+        if (crf_group_compute(group, &params, buffer)) throwBackendError("calculateCpu");
+        lastKernelMs = (crf_group_take_kernel_time(group, &ms, &launches) == CRF_OK && launches > 0) ? ms : -1.0;
+    } else {
+        crf_set_profiling(ctx, 1);
+        if (crf_compute(ctx, &params, buffer)) throwBackendError("calculateCpu");
+        lastKernelMs = (crf_take_kernel_time(ctx, &ms, &launches) == CRF_OK && launches > 0) ? ms : -1.0;
+    }
 }
 
 }  // namespace crfhost

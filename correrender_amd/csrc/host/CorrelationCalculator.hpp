@@ -57,6 +57,7 @@ public:
 
 protected:
     virtual void onCorrelationMemberCountChanged() {}
+    static const SettingBinding<ICorrelationCalculator> kSettings[12];
     std::vector<std::string> scalarFieldNames;
     int fieldIndex = 0, fieldIndexGui = 0;
     int fieldIndex2 = 0, fieldIndex2Gui = 0;
@@ -70,7 +71,7 @@ protected:
 
 class CorrelationCalculator : public ICorrelationCalculator {
 public:
-    /// device: HIP device ordinal the members are kept on.
+    /// device: HIP device ordinal the members are kept on (the "devices" setting may name several).
     explicit CorrelationCalculator(int device = 0);
     ~CorrelationCalculator() override;
     CalculatorType getCalculatorType() const override { return CalculatorType::CORRELATION; }
@@ -89,19 +90,24 @@ public:
     CorrelationMeasureType getCorrelationMeasureType() const { return correlationMeasureType; }
     int getKraskovNumNeighbors() const { return k; }
     int getKraskovNumNeighborsMax() const { return kMax; }
-    /// Kernel time of the last calculateCpu in ms (HIP events around the per-voxel kernel), < 0 if unavailable.
+    /// Kernel time of the last calculateCpu in ms (HIP events around the per-voxel kernels; slowest device of a group),
+    /// < 0 if unavailable.
     double getLastKernelTimeMs() const { return lastKernelMs; }
 
 protected:
     void onCorrelationMemberCountChanged() override;
 
 private:
+    static const SettingBinding<CorrelationCalculator> kSettings[7];
     void ensureMembersResident(int timeStepIdx, int ensembleIdx, int cs);
+    void releaseBackend();
     void uploadSecondaryMembers(int timeStepIdx, int ensembleIdx, int cs);
     [[noreturn]] void throwBackendError(const char* where);
 
-    int device;
+    int device;                 ///< default device ordinal (constructor)
+    std::vector<int> devices;   ///< "devices" setting; more than one entry = crf_group
     crf_context* ctx = nullptr;
+    crf_group* group = nullptr;
     // identity of the member set currently resident in HBM
     uint64_t residentGeneration = ~uint64_t(0);
     std::string residentField;

@@ -1,6 +1,7 @@
 // host_adapter_test.cpp -- driver used by tests/test_host_adapter.py.
 //   host_adapter_test settings                 CPU only: settings keys, defaults, naming, ranges, clamping
-//   host_adapter_test compute <in.bin> <dir>   GPU: runs scripted scenarios through VolumeData::getFieldEntryCpu ->
+//   host_adapter_test compute <in.bin> <dir> [devices]
+//                                              GPU: runs scripted scenarios through VolumeData::getFieldEntryCpu ->
 //                                              CorrelationCalculator::calculateCpu and dumps the fields for the
 //                                              Python side to compare with the oracle.
 // in.bin: int32 xs, ys, zs, ts, es, nfields; then for field f, time t, member e: xs*ys*zs float32.
@@ -99,6 +100,16 @@ static int testSettings() {
     SettingsMap o4;
     calc->getSettings(o4);
     CHECK(o4.getMap().at("device") == "Vulkan");
+    // "devices" (this backend's key): absent from the state while it is the single default device, round-trips otherwise
+    CHECK(o4.getMap().count("devices") == 0);
+    calc->setSettings(SettingsMap{{"devices", "0,1,2,3"}});
+    SettingsMap o5;
+    calc->getSettings(o5);
+    CHECK(o5.getMap().at("devices") == "0,1,2,3");
+    calc->setSettings(SettingsMap{{"devices", "0"}});
+    SettingsMap o6;
+    calc->getSettings(o6);
+    CHECK(o6.getMap().count("devices") == 0);
     // reference point clamps to the grid and marks dirty (CorrelationCalculator.cpp:190-202)
     (void)calc->getIsDirty();
     calc->setReferencePoint({100, -5, 3});
@@ -149,7 +160,7 @@ static void dump(const std::string& path, const float* v, size_t n) {
     f.write(reinterpret_cast<const char*>(v), std::streamsize(n * sizeof(float)));
 }
 
-static int testCompute(const char* inPath, const std::string& outDir) {
+static int testCompute(const char* inPath, const std::string& outDir, const char* devices) {
     std::ifstream f(inPath, std::ios::binary);
     int32_t h[6];
     f.read(reinterpret_cast<char*>(h), sizeof h);
@@ -161,6 +172,8 @@ static int testCompute(const char* inPath, const std::string& outDir) {
     auto vol = makeVolume(xs, ys, zs, ts, es, nf, &data);
     auto calc = std::make_shared<CorrelationCalculator>(0);
     vol->addCalculator(calc);
+    // optional: spread the grid over a device group ("0,0" = two z-slabs rehearsed on one GPU)
+    if (devices) calc->setSettings(SettingsMap{{"devices", devices}});
     auto eval = [&](const std::string& tag, int t, int e) {
         vol->updateCalculators();
         HostCacheEntry entry = vol->getFieldEntryCpu(FieldType::SCALAR, calc->getOutputFieldName(), t, e);
@@ -255,7 +268,7 @@ static int testNetCdf(const char* file, const std::string& outDir, bool compute)
 int main(int argc, char** argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "settings") return testSettings();
-        if (argc >= 4 && std::string(argv[1]) == "compute") return testCompute(argv[2], argv[3]);
+        if (argc >= 4 && std::string(argv[1]) == "compute") return testCompute(argv[2], argv[3], argc >= 5 ? argv[4] : nullptr);
         if (argc >= 4 && std::string(argv[1]) == "netcdf") return testNetCdf(argv[2], argv[3], false);
         if (argc >= 4 && std::string(argv[1]) == "netcdf_compute") return testNetCdf(argv[2], argv[3], true);
     } catch (const std::exception& e) {

@@ -352,3 +352,105 @@ class CorrField:
     def synth_box_member(self, out, xs, ys, zs_local, z_begin, zs_global, c, cs, seed, stream: int = 0):
         self._check(self._lib.crf_synth_box_member(self._ctx, C.c_void_p(out.data_ptr()), xs, ys, zs_local, z_begin,
                                                    zs_global, c, cs, C.c_uint64(seed), C.c_void_p(stream)))
+
+
+class CorrFieldGroup:
+    """Several GPUs behind one caller thread (crf_group_*): the whole grid in, the whole field out; the z-slab split,
+    the per-device worker threads and the reference-vector exchange (RCCL broadcast, or a peer copy when a device
+    ordinal repeats) live inside libcorrfield.  Mirrors CorrField.compute for host arrays."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._lib = load_library()
+        ords = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        rc = self._lib.crf_group_create(ords, len(devices), C.byref(g))
+        if rc != 0:
+            raise CorrFieldError(rc, (self._lib.crf_group_last_error(None) or b"").decode())
+        self._g = g
+        self.devices = [int(d) for d in devices]
+        self.grid = None
+        self.cs = 0
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CorrFieldError(rc, (self._lib.crf_group_last_error(self._g) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.crf_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def exchange(self) -> str:
+        return (self._lib.crf_group_exchange(self._g) or b"").decode()
+
+    def set_grid(self, xs: int, ys: int, zs: int, cs: int):
+        self._check(self._lib.crf_group_set_grid(self._g, xs, ys, zs, cs))
+        self.grid, self.cs = (xs, ys, zs), cs
+
+    def slab(self, slot: int):
+        z0, zn = C.c_int(), C.c_int()
+        self._check(self._lib.crf_group_slab(self._g, slot, C.byref(z0), C.byref(zn)))
+        return z0.value, zn.value
+
+    def _member_ptrs(self, members):
+        xs, ys, zs = self.grid
+        arrs = [np.ascontiguousarray(m, dtype=np.float32) for m in members]
+        if len(arrs) != self.cs or any(a.size != xs * ys * zs for a in arrs):
+            raise ValueError("members do not match the grid declared with set_grid")
+        return arrs, (C.c_void_p * self.cs)(*[a.ctypes.data for a in arrs])
+
+    def upload_members(self, members):
+        arrs, ptrs = self._member_ptrs(members)
+        self._check(self._lib.crf_group_upload_members(self._g, ptrs))
+
+    def upload_secondary_members(self, members):
+        arrs, ptrs = self._member_ptrs(members)
+        self._check(self._lib.crf_group_upload_secondary_members(self._g, ptrs))
+
+    def member_minmax(self):
+        mn, mx = C.c_float(), C.c_float()
+        self._check(self._lib.crf_group_member_minmax(self._g, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def secondary_member_minmax(self):
+        mn, mx = C.c_float(), C.c_float()
+        self._check(self._lib.crf_group_secondary_member_minmax(self._g, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def compute(self, measure, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
+                minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False,
+                absolute_value=False, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """calculateCpu(t, e, buffer) on all devices of the group; `ref` in GLOBAL grid coordinates."""
+        flags, mode = CorrField._mode_flags(symmetric, reference_from_secondary, absolute_value)
+        minmax_ref, minmax_query = CorrField._binned_ranges(self, measure, minmax_ref, minmax_query, mode)
+        p, keep = CorrField._params(self, measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                                    reference_values, flags)
+        xs, ys, zs = self.grid
+        if out is None:
+            out = np.empty((zs, ys, xs), dtype=np.float32)
+        elif out.dtype != np.float32 or out.size != xs * ys * zs or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 array of xs*ys*zs elements")
+        self._check(self._lib.crf_group_compute(self._g, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float))))
+        del keep
+        return out
+
+    def set_profiling(self, enabled: bool):
+        self._check(self._lib.crf_group_set_profiling(self._g, 1 if enabled else 0))
+
+    def take_kernel_time(self):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self._lib.crf_group_take_kernel_time(self._g, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -120,7 +120,8 @@ void crf_destroy(crf_context* ctx);
 /* Last error message of this context (or of the calling thread's last failed crf_create when ctx==NULL). */
 const char* crf_last_error(const crf_context* ctx);
 /* ABI version of this header, bumped on incompatible change. */
-int crf_abi_version(void);  /* 3: crf_params.reserved[0] became prepared_slot (same layout; 0 keeps the old meaning) */
+int crf_abi_version(void);  /* 4: crf_group_* (several devices behind one caller thread), crf_set_kraskov_noise;
+                               3: crf_params.reserved[0] became prepared_slot (same layout; 0 keeps the old meaning) */
 
 /* ---- the ensemble (replaces the fields[] gather of CorrelationCalculator.cpp:791-800) --------------------- */
 /* Declares the LOCAL grid (a whole grid, or this process's z-slab of one) and member count; drops any members. */
@@ -170,6 +171,45 @@ int crf_compute_device(crf_context* ctx, const crf_params* params, const void* d
 #define CRF_PREPARED_SLOTS 64
 int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* device_reference_values, int slot,
                        void* stream);
+
+/* ---- several GPUs behind ONE caller thread ------------------------------------------------------------------------
+ * The reference is a single process that calls its calculators from the render thread with a caller-owned host buffer
+ * (src/Volume/VolumeData.cpp:1214-1226, 1469-1472).  A crf_group gives such a caller N devices: the GLOBAL grid is cut
+ * into z-slabs (the first zs % N slabs one slice longer -- with x-fastest volumes a slab of every member is contiguous
+ * and the result slabs concatenate in the caller's buffer), each device keeps its slab of every member resident in its
+ * own HBM and is driven by its own worker thread inside the library, and every evaluation has one exchange step: the
+ * device whose slab holds the reference point gathers the cs reference values (CorrelationCalculator.cpp:802,815-817)
+ * and broadcasts them -- ncclBroadcast on a persistent single-process RCCL communicator over xGMI when the ordinals
+ * are distinct, a stream-ordered peer copy when an ordinal repeats (a rehearsal of N slabs on fewer GPUs) or when the
+ * environment says CRF_GROUP_EXCHANGE=peer.  Each device then evaluates its slab and copies it straight into its part
+ * of the caller's buffer (the copies of the N devices run concurrently).  Results are bit-identical to a single
+ * context's.  Same conventions as above: one caller thread, status codes, crf_group_last_error. */
+typedef struct crf_group crf_group;
+int crf_group_create(const int* device_ordinals, int num_devices, crf_group** out_group);
+void crf_group_destroy(crf_group* group);
+const char* crf_group_last_error(const crf_group* group);   /* group == NULL: last failed crf_group_create of this thread */
+int crf_group_size(const crf_group* group);
+/* "rccl (...)", "peer copy (...)" or "none (one device)": how the reference vector travels. */
+const char* crf_group_exchange(const crf_group* group);
+/* The context that drives device slot `slot` (its LOCAL grid is the slab): for per-device helpers such as
+ * crf_bind_members_device or crf_last_kernel_name.  Owned by the group. */
+crf_context* crf_group_context(crf_group* group, int slot);
+/* Declares the GLOBAL grid and member count (zs >= number of devices); drops any members. */
+int crf_group_set_grid(crf_group* group, int xs, int ys, int zs, int cs);
+int crf_group_slab(const crf_group* group, int slot, int* z_begin, int* z_count);
+/* cs host volumes of the WHOLE grid; every device uploads its slab of each (concurrently). */
+int crf_group_upload_members(crf_group* group, const float* const* host_members);
+int crf_group_upload_secondary_members(crf_group* group, const float* const* host_members);
+/* Extrema over all slabs (binned-MI normalisation range, CorrelationCalculator.cpp:822-829). */
+int crf_group_member_minmax(crf_group* group, float* out_min, float* out_max);
+int crf_group_secondary_member_minmax(crf_group* group, float* out_min, float* out_max);
+/* calculateCpu(t, e, buffer) on N devices: params as for crf_compute with the reference point in GLOBAL coordinates;
+ * host_out receives xs*ys*zs floats.  Supports the reference point, a host reference vector (no exchange),
+ * CRF_FLAG_REFERENCE_FROM_SECONDARY, CRF_FLAG_SYMMETRIC (no exchange) and CRF_FLAG_ABSOLUTE_VALUE. */
+int crf_group_compute(crf_group* group, const crf_params* params, float* host_out);
+int crf_group_set_profiling(crf_group* group, int enabled);
+/* Slowest device's summed kernel time (ms) and its launch count since the last call. */
+int crf_group_take_kernel_time(crf_group* group, double* out_ms_max, int* out_launches);
 
 /* ---- pair-request evaluation (CorrelationComputePass request mode, CorrelationCalculator.hpp:250-258; CPU twin
  * HEBChart::computeCorrelations, src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600) ---------------------------- */

@@ -20,16 +20,37 @@ def test_settings_defaults_naming_and_clamping():
     assert r.returncode == 0 and "SETTINGS-OK" in r.stdout, r.stderr
 
 
-def _run_compute(tmp_path, data):
-    """data: float32 [nfields, ts, es, zs, ys, xs]"""
+def _run_compute(tmp_path, data, devices=None):
+    """data: float32 [nfields, ts, es, zs, ys, xs]; devices: value of the adapter's "devices" setting (a device group)"""
     nf, ts, es, zs, ys, xs = data.shape
+    tmp_path.mkdir(exist_ok=True)
     inp = tmp_path / "in.bin"
     with open(inp, "wb") as f:
         np.array([xs, ys, zs, ts, es, nf], np.int32).tofile(f)
         np.ascontiguousarray(data, np.float32).tofile(f)
-    r = subprocess.run([str(EXE), "compute", str(inp), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    cmd = [str(EXE), "compute", str(inp), str(tmp_path)] + ([devices] if devices else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "COMPUTE-OK" in r.stdout, r.stdout + r.stderr
     return lambda tag: np.fromfile(tmp_path / f"{tag}.bin", np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_calculate_cpu_on_a_device_group_is_bit_identical(tmp_path, devices):
+    """The adapter's `devices` setting: calculateCpu over a crf_group (z-slabs, one worker per slot; two / three slots
+    rehearsed on the box's one GPU) -- every scripted scenario, all seven measures, the SEPARATE / time-lag /
+    SEPARATE_SYMMETRIC modes -- must reproduce the single-context fields bit for bit."""
+    xs, ys, zs, cs = 24, 16, 7, 32
+    a = synth.box_ensemble(xs, ys, zs, cs, seed=51)
+    b = synth.box_ensemble(xs, ys, zs, cs, seed=52)
+    data = np.stack([np.stack([a * 0.5 + 1.0, a]), np.stack([b, b * 2.0])])
+    single = _run_compute(tmp_path / "single", data)
+    group = _run_compute(tmp_path / "group", data, devices)
+    tags = ["m_pearson", "m_spearman", "m_kendall", "m_mi_binned", "m_mi_kraskov", "m_binned_mi_correlation_coefficient",
+            "m_kmi_correlation_coefficient", "pearson_ref123", "kraskov2_k3_ref123", "spearman_separate",
+            "binned_separate", "pearson_separate_lag0", "kendall_symmetric", "binned_symmetric"]
+    for tag in tags:
+        assert_bit_exact(group(tag), single(tag), f"adapter on devices={devices}: {tag}")
 
 
 @pytest.mark.gpu

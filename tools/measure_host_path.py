@@ -1,55 +1,79 @@
 #!/usr/bin/env python3
-"""Times crf_compute (host output buffer: kernel + D2H of 4 bytes/voxel + sync) next to crf_compute_device at
-256^3 x 64 -- the PCIe-inclusive rate quoted in DESIGN.md (never bench.py's `value`)."""
+"""Times crf_compute (host output buffer: kernel + D2H of 4 bytes/voxel) at 256^3 x 64 into a resident and into a
+fresh destination, for several (voxel ranges, copier threads) settings -- the PCIe-inclusive rate of DESIGN.md / the
+host_boundary record of bench.py (never bench.py's `value`).  One process per setting (the range tables are built once
+per context)."""
+import json
+import os
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-import numpy as np
-import torch
-import correrender_amd as ca
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 
-xs = ys = zs = 256
-cs = 64
-eng = ca.CorrField(0)
-eng.set_grid(xs, ys, zs, cs)
-members = torch.empty((cs, zs, ys, xs), dtype=torch.float32, device="cuda")
-for c in range(cs):
-    eng.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, 1)
-torch.cuda.synchronize()
-eng.bind_members(members)
-for measure in (ca.Measure.PEARSON,):
-    for _ in range(3):
-        eng.compute(measure, (10, 20, 30))
-    t0 = time.perf_counter()
-    n = 20
+
+def one():
+    import numpy as np
+    import torch
+    import correrender_amd as ca
+    xs = ys = zs = 256
+    cs = 64
+    measure = ca.Measure(ca.MEASURE_IDS.index(os.environ.get("CRF_MEASURE", "pearson")))
+    eng = ca.CorrField(0)
+    eng.set_grid(xs, ys, zs, cs)
+    members = torch.empty((cs, zs, ys, xs), dtype=torch.float32, device="cuda")
+    for c in range(cs):
+        eng.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, 1)
+    torch.cuda.synchronize()
+    eng.bind_members(members)
+    kw = dict(k=3) if "kraskov" in measure.name.lower() else {}
+    resident = np.zeros((zs, ys, xs), np.float32)
+    for i in range(3):
+        eng.compute(measure, (10, 20, 30), out=resident, **kw)
+    n = int(os.environ.get("CRF_REPS", "15"))
+    t_res, t_fresh = [], []
     for i in range(n):
-        eng.compute(measure, (10 + i, 20, 30))
-    dt = (time.perf_counter() - t0) / n
-    print(f"{measure.name}: crf_compute (host buffer, pageable) {dt * 1e3:.3f} ms/evaluation = {xs * ys * zs / dt / 1e6:.0f} Mvoxel-corr/s")
+        t0 = time.perf_counter()
+        eng.compute(measure, (10 + i, 20, 30), out=resident, **kw)
+        t_res.append(time.perf_counter() - t0)
+    for i in range(n):
+        fresh = np.empty((zs, ys, xs), np.float32)
+        t0 = time.perf_counter()
+        eng.compute(measure, (10 + i, 20, 30), out=fresh, **kw)
+        t_fresh.append(time.perf_counter() - t0)
+        del fresh
     out = torch.empty(xs * ys * zs, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        eng.compute_device(measure, out, (10 + i, 20, 30), stream=torch.cuda.current_stream().cuda_stream)
+        eng.compute_device(measure, out, (10 + i, 20, 30), stream=torch.cuda.current_stream().cuda_stream, **kw)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    print(f"{measure.name}: crf_compute_device {dt * 1e3:.3f} ms/evaluation = {xs * ys * zs / dt / 1e6:.0f} Mvoxel-corr/s")
+    dev = (time.perf_counter() - t0) / n
+    med = lambda v: sorted(v)[len(v) // 2]
+    print(json.dumps({"chunks": os.environ.get("CRF_HOST_CHUNKS", "auto"), "threads": os.environ.get("CRF_COPY_THREADS", "auto"),
+                      "resident_ms": round(med(t_res) * 1e3, 3), "resident_min_ms": round(min(t_res) * 1e3, 3),
+                      "fresh_ms": round(med(t_fresh) * 1e3, 3), "device_only_ms": round(dev * 1e3, 3)}))
 
-# the same with ONE reused (already touched) destination buffer: isolates first-touch page faults of a fresh buffer
-import ctypes as C
-from correrender_amd._lib import CrfParams
-buf = np.empty(xs * ys * zs, np.float32)
-p = CrfParams()
-p.measure = 0
-p.ref_x, p.ref_y, p.ref_z = 10, 20, 30
-ptr = buf.ctypes.data_as(C.POINTER(C.c_float))
-for _ in range(3):
-    eng._lib.crf_compute(eng._ctx, C.byref(p), ptr)
-t0 = time.perf_counter()
-for i in range(n):
-    p.ref_x = 10 + i
-    eng._lib.crf_compute(eng._ctx, C.byref(p), ptr)
-dt = (time.perf_counter() - t0) / n
-print(f"PEARSON: crf_compute into a reused host buffer {dt * 1e3:.3f} ms/evaluation = {xs * ys * zs / dt / 1e6:.0f} Mvoxel-corr/s")
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        one()
+    else:
+        import torch
+        d = torch.empty(256 ** 3, dtype=torch.float32, device="cuda")
+        h = torch.empty(256 ** 3, dtype=torch.float32).pin_memory()
+        for _ in range(3):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        print(json.dumps({"pure_dma_d2h_pinned_ms": round(dt * 1e3, 3), "GB/s": round(d.numel() * 4 / dt / 1e9, 1)}))
+        del d, h
+        for chunks, threads in [("1", "8"), ("8", "4"), ("8", "8"), ("16", "4"), ("16", "8"), ("16", "12")]:
+            env = dict(os.environ, CRF_HOST_CHUNKS=chunks, CRF_COPY_THREADS=threads)
+            subprocess.run([sys.executable, __file__, "one"], env=env, check=True)
