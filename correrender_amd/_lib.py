@@ -81,6 +81,8 @@ SYMBOLS = {
     "crf_last_kernel_name": (C.c_char_p, [_VOIDP]),
     "crf_synth_box_member": (C.c_int, [_VOIDP, _VOIDP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_uint64, _VOIDP]),
+    "crf_set_kraskov_noise": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "crf_group_set_kraskov_noise": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     # several devices behind one caller thread
     "crf_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_VOIDP)]),
     "crf_group_destroy": (None, [_VOIDP]),

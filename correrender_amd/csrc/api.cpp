@@ -286,6 +286,31 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     return CRF_OK;
 }
 
+int crf_set_kraskov_noise(crf_context* c, const double* ref_noise, const double* query_noise) {
+    if (!c) return CRF_ERR_ARGUMENT;
+    if (c->cs <= 0 || !c->d_tables) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    if ((ref_noise == nullptr) != (query_noise == nullptr))
+        return fail(c, CRF_ERR_ARGUMENT, "crf_set_kraskov_noise: give both tables, or NULL for both (default stream)");
+    if (int r = bind_device(c)) return r;
+    const size_t cs = size_t(c->cs);
+    std::vector<double> both(2 * cs);
+    if (ref_noise) {
+        for (size_t e = 0; e < cs; e++) {
+            // the estimator's contract: a jitter far below the data's resolution, never negative
+            if (!(ref_noise[e] >= 0.0 && ref_noise[e] < 1e-9) || !(query_noise[e] >= 0.0 && query_noise[e] < 1e-9))
+                return fail(c, CRF_ERR_ARGUMENT, fmt("crf_set_kraskov_noise: entry %zu outside [0, 1e-9)", e));
+            both[e] = ref_noise[e];
+            both[cs + e] = query_noise[e];
+        }
+    } else {
+        const std::vector<double> t = build_tables(c->cs);
+        std::copy(t.begin() + 2 * (c->cs + 1), t.end(), both.begin());
+    }
+    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    CRF_HIP(c, hipMemcpy(c->d_tables + 2 * (cs + 1), both.data(), both.size() * sizeof(double), hipMemcpyHostToDevice));
+    return CRF_OK;
+}
+
 int crf_upload_members(crf_context* c, const float* const* host_members) {
     if (!c || !host_members) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");

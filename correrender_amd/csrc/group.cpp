@@ -376,6 +376,12 @@ int crf_group_secondary_member_minmax(crf_group* g, float* out_min, float* out_m
     return group_minmax(g, true, out_min, out_max);
 }
 
+int crf_group_set_kraskov_noise(crf_group* g, const double* ref_noise, const double* query_noise) {
+    if (!g) return CRF_ERR_ARGUMENT;
+    const int status = g->workers->run([&](int r) -> int { return crf_set_kraskov_noise(g->ctx[size_t(r)], ref_noise, query_noise); });
+    return collect(g, status, "crf_group_set_kraskov_noise");
+}
+
 int crf_group_set_profiling(crf_group* g, int enabled) {
     if (!g) return CRF_ERR_ARGUMENT;
     for (crf_context* c : g->ctx) crf_set_profiling(c, enabled);

@@ -108,6 +108,20 @@ class CorrField:
         self._check(self._lib.crf_member_minmax(self._ctx, C.byref(mn), C.byref(mx)))
         return mn.value, mx.value
 
+    def set_kraskov_noise(self, ref_noise=None, query_noise=None):
+        """Replaces the per-member tie-breaking noise tables of the Kraskov estimators (noise VALUES, i.e. u * 1e-10,
+        cs doubles each) -- e.g. with the stream of the reference's own sgl::XorshiftRandomGenerator; None restores the
+        library's documented default stream (crf_set_kraskov_noise)."""
+        if ref_noise is None:
+            self._check(self._lib.crf_set_kraskov_noise(self._ctx, None, None))
+            return
+        r = np.ascontiguousarray(ref_noise, np.float64)
+        q = np.ascontiguousarray(query_noise, np.float64)
+        if r.size != self.cs or q.size != self.cs:
+            raise ValueError("noise tables must hold cs doubles each")
+        self._check(self._lib.crf_set_kraskov_noise(self._ctx, r.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    q.ctypes.data_as(C.POINTER(C.c_double))))
+
     # -- secondary members: the second scalar field of the SEPARATE / SEPARATE_SYMMETRIC field modes ---------
     def upload_secondary_members(self, members: Sequence[np.ndarray]):
         arrs = [np.ascontiguousarray(m, dtype=np.float32) for m in members]

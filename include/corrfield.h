@@ -153,6 +153,17 @@ int crf_gather_reference_device(crf_context* ctx, int x, int y, int z, void* dev
  * z-slice another process owns) -- so that one all-reduce(sum) over the processes yields every row everywhere. */
 int crf_gather_reference_rows_device(crf_context* ctx, const int32_t* xyz, int num_rows, void* device_rows, void* stream);
 
+/* ---- Kraskov tie-breaking noise ------------------------------------------------------------------------------------
+ * The KSG estimators add `u * 1e-10`, u drawn per member from sgl::XorshiftRandomGenerator(617406168) for the reference
+ * vector and (864730169) for every query vector, to break exact ties (MutualInformation.cpp:409-420, 167-185).  sgl is
+ * not vendored by the reference and not available to this build, so the library's DEFAULT tables come from a
+ * documented stand-in stream (Marsaglia xorshift32) -- results on exactly tied data then differ from a
+ * reference build in the last digits.  An integrator who has sgl passes the real stream here: ref_noise[e] and
+ * query_noise[e] are the noise VALUES (already multiplied by 1e-10, as double) of member e, cs of each; both NULL
+ * restores the default.  Applies to every later Kraskov evaluation of this context (field, symmetric and pair-request
+ * modes) until the next crf_set_grid.  Stream-ordered on the context's own stream; call it between evaluations. */
+int crf_set_kraskov_noise(crf_context* ctx, const double* ref_noise, const double* query_noise);
+
 /* ---- evaluation (replaces the hot loop CorrelationCalculator.cpp:868-1142) ------------------------------- */
 /* Synchronous, host output: what calculateCpu(t, e, buffer) does.  host_out receives xs*ys*zs floats. */
 int crf_compute(crf_context* ctx, const crf_params* params, float* host_out);
@@ -210,6 +221,8 @@ int crf_group_compute(crf_group* group, const crf_params* params, float* host_ou
 int crf_group_set_profiling(crf_group* group, int enabled);
 /* Slowest device's summed kernel time (ms) and its launch count since the last call. */
 int crf_group_take_kernel_time(crf_group* group, double* out_ms_max, int* out_launches);
+/* crf_set_kraskov_noise on every device of the group. */
+int crf_group_set_kraskov_noise(crf_group* group, const double* ref_noise, const double* query_noise);
 
 /* ---- pair-request evaluation (CorrelationComputePass request mode, CorrelationCalculator.hpp:250-258; CPU twin
  * HEBChart::computeCorrelations, src/Renderers/Diagram/HEBChartCorrelation.cpp:493-600) ---------------------------- */

@@ -270,9 +270,18 @@ struct KraskovScratch {
     DigammaTable psi;
 };
 
+// Optional replacement of the noise tables (oracle_set_kraskov_noise): noise values in [0, 1e-10) per member, e.g. the
+// stream of the reference's own generator produced by a build that has sgl.  Read-only while fields are evaluated.
+std::vector<double> g_noise_override[2];
+
 void noisy_coords(const float* v, int n, uint32_t seed, std::vector<double>& out) {
-    Xorshift32 g(seed);
     out.resize(size_t(n));
+    const std::vector<double>& over = g_noise_override[seed == SEED_REF ? 0 : 1];
+    if (int(over.size()) >= n) {
+        for (int e = 0; e < n; e++) out[size_t(e)] = double(v[e]) + over[size_t(e)];
+        return;
+    }
+    Xorshift32 g(seed);
     for (int e = 0; e < n; e++) out[size_t(e)] = double(v[e]) + double(g.next01()) * NOISE_SCALE;
 }
 
@@ -506,6 +515,12 @@ double oracle_digamma_int(int n) {
     DigammaTable t;
     t.ensure(std::max(n, 1));
     return t.v[size_t(n)];
+}
+// Replaces the per-member tie-breaking noise (values already scaled, i.e. u * 1e-10) of the reference / query vector
+// for every later Kraskov evaluation; n == 0 restores the documented default stream.  Mirrors crf_set_kraskov_noise.
+void oracle_set_kraskov_noise(const double* ref_noise, const double* query_noise, int n) {
+    g_noise_override[0].assign(ref_noise, ref_noise + (n > 0 ? n : 0));
+    g_noise_override[1].assign(query_noise, query_noise + (n > 0 ? n : 0));
 }
 // u_e of the documented noise stream (which = 0: reference vector, 1: query vector)
 void oracle_noise01(int which, int n, float* out) {

@@ -38,6 +38,8 @@ class Oracle:
         lib.oracle_mi_kraskov.argtypes = [FP, FP, C.c_int, C.c_int, C.c_int]
         lib.oracle_digamma_int.restype = C.c_double
         lib.oracle_digamma_int.argtypes = [C.c_int]
+        lib.oracle_set_kraskov_noise.restype = None
+        lib.oracle_set_kraskov_noise.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         lib.oracle_noise01.restype = None
         lib.oracle_noise01.argtypes = [C.c_int, C.c_int, FP]
         lib.oracle_minmax.restype = None
@@ -93,6 +95,17 @@ class Oracle:
 
     def digamma(self, n):
         return float(self.lib.oracle_digamma_int(int(n)))
+
+    def set_kraskov_noise(self, ref_noise=None, query_noise=None):
+        """Per-member noise tables (already scaled by 1e-10) for the Kraskov estimators; None restores the default."""
+        if ref_noise is None:
+            self.lib.oracle_set_kraskov_noise(None, None, 0)
+            return
+        r = np.ascontiguousarray(ref_noise, np.float64)
+        q = np.ascontiguousarray(query_noise, np.float64)
+        assert r.size == q.size
+        self.lib.oracle_set_kraskov_noise(r.ctypes.data_as(C.POINTER(C.c_double)), q.ctypes.data_as(C.POINTER(C.c_double)),
+                                          r.size)
 
     def noise01(self, which, n):
         out = np.empty(n, np.float32)
