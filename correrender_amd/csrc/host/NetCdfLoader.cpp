@@ -2,8 +2,11 @@
 // magic numrecs dim_list gatt_list var_list; all integers big-endian, names and values padded to 4 bytes).
 #include "NetCdfLoader.hpp"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -80,31 +83,141 @@ bool isOneOf(const std::string& s, std::initializer_list<const char*> names) {
 }
 }  // namespace
 
+// ---- netcdf-c through dlopen (NetCDF-4 / CDF-5 files) ------------------------------------------------------------
+// The handful of entry points of the library's stable C API that the reference's loader uses as well
+// (NetCdfLoader.cpp:282-339 nc_open / nc_inq / nc_inq_dim / nc_inq_var, :93-99 and :826-935 nc_get_vara_float,
+// :753-765 nc_get_att_text / nc_get_att_float).  nc_type values are those of netcdf.h and equal the classic tags above.
+struct NetCdfLoader::Library {
+    void* handle = nullptr;
+    int (*open)(const char*, int, int*) = nullptr;
+    int (*close)(int) = nullptr;
+    int (*inq)(int, int*, int*, int*, int*) = nullptr;
+    int (*inq_dim)(int, int, char*, size_t*) = nullptr;
+    int (*inq_var)(int, int, char*, int*, int*, int*, int*) = nullptr;
+    int (*inq_att)(int, int, const char*, int*, size_t*) = nullptr;
+    int (*get_att_text)(int, int, const char*, char*) = nullptr;
+    int (*get_att_float)(int, int, const char*, float*) = nullptr;
+    int (*get_vara_float)(int, int, const size_t*, const size_t*, float*) = nullptr;
+    const char* (*strerror)(int) = nullptr;
+    std::string tried;
+    bool load() {
+        std::vector<std::string> names;
+        if (const char* env = std::getenv("CRF_LIBNETCDF"); env && *env) names.push_back(env);
+        for (const char* n : {"libnetcdf.so", "libnetcdf.so.19", "libnetcdf.so.18", "libnetcdf.so.15", "libnetcdf.so.13",
+                              "libnetcdf.so.11", "libnetcdf.so.7"})
+            names.push_back(n);
+        for (const std::string& n : names) {
+            handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+            tried += (tried.empty() ? "" : ", ") + n;
+        }
+        if (!handle) return false;
+        auto sym = [&](const char* name) { return dlsym(handle, name); };
+        open = reinterpret_cast<decltype(open)>(sym("nc_open"));
+        close = reinterpret_cast<decltype(close)>(sym("nc_close"));
+        inq = reinterpret_cast<decltype(inq)>(sym("nc_inq"));
+        inq_dim = reinterpret_cast<decltype(inq_dim)>(sym("nc_inq_dim"));
+        inq_var = reinterpret_cast<decltype(inq_var)>(sym("nc_inq_var"));
+        inq_att = reinterpret_cast<decltype(inq_att)>(sym("nc_inq_att"));
+        get_att_text = reinterpret_cast<decltype(get_att_text)>(sym("nc_get_att_text"));
+        get_att_float = reinterpret_cast<decltype(get_att_float)>(sym("nc_get_att_float"));
+        get_vara_float = reinterpret_cast<decltype(get_vara_float)>(sym("nc_get_vara_float"));
+        strerror = reinterpret_cast<decltype(strerror)>(sym("nc_strerror"));
+        return open && close && inq && inq_dim && inq_var && inq_att && get_att_text && get_att_float && get_vara_float;
+    }
+    ~Library() {
+        if (handle) dlclose(handle);
+    }
+};
+
+void NetCdfLoader::openWithLibrary(const char* why) {
+    if (file) std::fclose(file);
+    file = nullptr;
+    library = std::make_unique<Library>();
+    if (!library->load()) {
+        const std::string tried = library->tried;
+        const bool found = library->handle != nullptr;
+        library.reset();
+        error(std::string(why) + " is read through the netcdf-c library, which " +
+              (found ? "lacks the expected nc_* entry points" : "was not found (tried " + tried + ")") +
+              "; install libnetcdf or set CRF_LIBNETCDF, or convert the file with `nccopy -k classic`");
+    }
+    auto check = [&](int status, const char* what) {
+        if (status != 0)
+            error(std::string(what) + " failed: " + (library->strerror ? library->strerror(status) : "netcdf error " + std::to_string(status)));
+    };
+    check(library->open(path.c_str(), 0 /* NC_NOWRITE */, &ncid), "nc_open");
+    int ndims = 0, nvars = 0, ngatts = 0, unlimited = -1;
+    check(library->inq(ncid, &ndims, &nvars, &ngatts, &unlimited), "nc_inq");
+    char name[257];
+    for (int d = 0; d < ndims; d++) {
+        size_t len = 0;
+        check(library->inq_dim(ncid, d, name, &len), "nc_inq_dim");
+        dims.push_back(Dim{name, uint64_t(len)});  // the CURRENT length, also for an unlimited dimension
+    }
+    for (int i = 0; i < nvars; i++) {
+        Var v;
+        int type = 0, rank = 0, natts = 0;
+        int dimids[1024];
+        check(library->inq_var(ncid, i, name, &type, &rank, dimids, &natts), "nc_inq_var");
+        v.name = name;
+        v.type = type;
+        v.varid = i;
+        v.dimids.assign(dimids, dimids + rank);
+        int atype = 0;
+        size_t alen = 0;
+        if (library->inq_att(ncid, i, "standard_name", &atype, &alen) == 0 && atype == NC_CHAR && alen < (1u << 16)) {
+            std::string text(alen, '\0');
+            check(library->get_att_text(ncid, i, "standard_name", text.data()), "nc_get_att_text");
+            while (!text.empty() && text.back() == '\0') text.pop_back();
+            v.standardName = text;
+        }
+        for (const char* fill : {"missing_value", "_FillValue"}) {  // the later one wins, as in the classic path
+            if (library->inq_att(ncid, i, fill, &atype, &alen) == 0 && alen >= 1 && (atype == NC_FLOAT || atype == NC_DOUBLE)) {
+                std::vector<float> values(alen);
+                check(library->get_att_float(ncid, i, fill, values.data()), "nc_get_att_float");
+                v.hasFill = true;
+                v.fillValue = values[0];
+            }
+        }
+        vars.push_back(std::move(v));
+    }
+}
+
 void NetCdfLoader::error(const std::string& msg) const {
     throw CalculatorError("Error in NetCdfLoader: " + msg + " (file \"" + path + "\").");
 }
 
 NetCdfLoader::~NetCdfLoader() {
     if (file) std::fclose(file);
+    if (library && ncid >= 0) library->close(ncid);
 }
 
 uint64_t NetCdfLoader::dimLength(int dimid) const {
     const Dim& d = dims.at(size_t(dimid));
-    return d.length == 0 ? numRecs : d.length;
+    return (d.length == 0 && !library) ? numRecs : d.length;
 }
 
 NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
     file = std::fopen(path.c_str(), "rb");
     if (!file) error("file could not be opened");
+    unsigned char magic[4] = {0, 0, 0, 0};
+    if (std::fread(magic, 1, 4, file) != 4) error("truncated header");
+    if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') {
+        openWithLibrary("NetCDF-4 (an HDF5 container)");
+    } else if (magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F' && magic[3] == 5) {
+        openWithLibrary("CDF-5 (64-bit data)");
+    } else {
+        if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F') error("not a NetCDF file");
+        version = magic[3];
+        if (version != 1 && version != 2) error("unknown NetCDF classic version byte");
+        parseClassicHeader();
+    }
+    deriveGridAndFields();
+}
+
+void NetCdfLoader::parseClassicHeader() {
     Cursor c{file, path};
-    unsigned char magic[4];
-    c.bytes(magic, 4);
-    if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F')
-        error("NetCDF-4 (HDF5 container) is not supported by this build (no libhdf5); convert with `nccopy -k classic`");
-    if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F') error("not a NetCDF classic file");
-    version = magic[3];
-    if (version == 5) error("CDF-5 (64-bit data) is not supported; convert with `nccopy -k 64-bit-offset`");
-    if (version != 1 && version != 2) error("unknown NetCDF classic version byte");
     const uint32_t recs = c.u32();
     numRecs = recs == 0xFFFFFFFFu ? 0 : recs;  // STREAMING: record count not recorded; fixed by the file size below
 
@@ -113,6 +226,12 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
         if (tag == 0 && n == 0) return 0;  // ABSENT
         if (tag != expectedTag) error("malformed header (unexpected list tag)");
         return n;
+    };
+    struct Attr {
+        std::string name;
+        int type;
+        std::vector<unsigned char> raw;  // big-endian values
+        uint64_t nelems;
     };
     auto readAttrs = [&](std::vector<Attr>& out) {
         const uint32_t n = listHeader(TAG_ATTRIBUTE);
@@ -152,7 +271,22 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
             if (id >= dims.size()) error("variable \"" + v.name + "\" refers to an unknown dimension");
             v.dimids.push_back(int(id));
         }
-        readAttrs(v.attrs);
+        std::vector<Attr> attrs;
+        readAttrs(attrs);
+        for (const Attr& a : attrs) {
+            if (a.name == "standard_name" && a.type == NC_CHAR) {
+                v.standardName.assign(reinterpret_cast<const char*>(a.raw.data()), a.raw.size());
+                while (!v.standardName.empty() && v.standardName.back() == '\0') v.standardName.pop_back();
+            } else if ((a.name == "missing_value" || a.name == "_FillValue") && a.nelems >= 1) {
+                if (a.type == NC_FLOAT) {
+                    v.hasFill = true;
+                    v.fillValue = beFloat(a.raw.data());
+                } else if (a.type == NC_DOUBLE) {
+                    v.hasFill = true;
+                    v.fillValue = float(beDouble(a.raw.data()));
+                }
+            }
+        }
         v.type = int(c.u32());
         v.vsize = c.u32();
         v.begin = version == 1 ? uint64_t(c.u32()) : c.u64();
@@ -178,8 +312,11 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
         const uint64_t size = uint64_t(std::ftell(file));
         numRecs = size > firstBegin ? (size - firstBegin) / recordSize : 0;
     }
+}
 
-    // grid: first float/double variable with (z, y, x) trailing dimensions
+// Common to both back ends: the grid from the first float/double variable with (z, y, x) trailing dimensions, the
+// member / time axis, the field list.
+void NetCdfLoader::deriveGridAndFields() {
     int representative = -1;
     for (size_t i = 0; i < vars.size() && representative < 0; i++) {
         const Var& v = vars[i];
@@ -220,21 +357,8 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
             int(dimLength(v.dimids[r - 1])) != xs)
             continue;
         if (r == 4 && int(dimLength(v.dimids[0])) != (ts > 1 ? ts : es) && !(ts == 1 && es == 1)) continue;
-        Field f{v.name, int(i), false, std::numeric_limits<float>::quiet_NaN()};
-        for (const Attr& a : v.attrs) {
-            if (a.name == "standard_name" && a.type == NC_CHAR) {
-                f.name.assign(reinterpret_cast<const char*>(a.raw.data()), a.raw.size());
-                while (!f.name.empty() && f.name.back() == '\0') f.name.pop_back();
-            } else if ((a.name == "missing_value" || a.name == "_FillValue") && a.nelems >= 1) {
-                if (a.type == NC_FLOAT) {
-                    f.hasFill = true;
-                    f.fillValue = beFloat(a.raw.data());
-                } else if (a.type == NC_DOUBLE) {
-                    f.hasFill = true;
-                    f.fillValue = float(beDouble(a.raw.data()));
-                }
-            }
-        }
+        Field f{v.standardName.empty() ? v.name : v.standardName, int(i), v.hasFill,
+                v.hasFill ? v.fillValue : std::numeric_limits<float>::quiet_NaN()};
         fields.push_back(f);
         fieldNames.push_back(f.name);
     }
@@ -243,6 +367,16 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
 // one xs*ys*zs slab: the whole variable (rank 3) or index `leadingIndex` of its first dimension (rank 4)
 void NetCdfLoader::readSlab(const Var& v, uint64_t leadingIndex, float* out) const {
     const uint64_t n = uint64_t(xs) * uint64_t(ys) * uint64_t(zs);
+    if (library) {  // netcdf-c converts NC_DOUBLE to float itself (the reference's loadFloatArray3D/4D, :93-120)
+        const bool lead = v.dimids.size() == 4;
+        if (lead && leadingIndex >= dimLength(v.dimids[0])) error("index outside the leading dimension of \"" + v.name + "\"");
+        const size_t start4[4] = {size_t(leadingIndex), 0, 0, 0}, count4[4] = {1, size_t(zs), size_t(ys), size_t(xs)};
+        const int status = library->get_vara_float(ncid, v.varid, lead ? start4 : start4 + 1, lead ? count4 : count4 + 1, out);
+        if (status != 0)
+            error("nc_get_vara_float failed on \"" + v.name + "\": " +
+                  (library->strerror ? library->strerror(status) : "netcdf error " + std::to_string(status)));
+        return;
+    }
     const size_t es_ = typeSize(v.type);
     uint64_t offset = v.begin;
     if (v.dimids.size() == 4) {

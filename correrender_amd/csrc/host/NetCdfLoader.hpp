@@ -3,10 +3,16 @@
 // (scripts/generate_synth_box_ensembles.py:151-158) and read by its NetCdfLoader
 // (src/Loaders/NetCdfLoader.cpp:286-560 setInputFiles, :826-935 getFieldEntry).
 //
-// The reference links libnetcdf; this image has neither libnetcdf nor libhdf5, so the CLASSIC file formats are parsed
-// directly: CDF-1 (32-bit offsets) and CDF-2 (64-bit offsets), fixed-size and record (UNLIMITED first dimension)
-// variables, NC_FLOAT / NC_DOUBLE data.  NetCDF-4 files (HDF5 containers, which `format='NETCDF4_CLASSIC'` produces)
-// and CDF-5 are recognised and rejected with a message naming the conversion (`nccopy -k classic`).
+// Two back ends behind one metadata model:
+//   * the CLASSIC file formats are parsed directly, without any library: CDF-1 (32-bit offsets) and CDF-2 (64-bit
+//     offsets), fixed-size and record (UNLIMITED first dimension) variables, NC_FLOAT / NC_DOUBLE data;
+//   * NetCDF-4 files (HDF5 containers -- what the generator's `format='NETCDF4_CLASSIC'` writes and what the paper's data
+//     sets are) and CDF-5 go through the netcdf-c library the reference itself links (nc_open ... nc_get_vara_float,
+//     NetCdfLoader.cpp:282-339, 826-935), loaded at RUN TIME with dlopen: every machine that runs the reference has
+//     it.  Library name: $CRF_LIBNETCDF, else libnetcdf.so[.19|.18|.15|.13|.11|.7].  Without the library such a file is
+//     rejected with a message that says so and names the conversion (`nccopy -k classic`).  This build image has
+//     neither libnetcdf nor libhdf5 nor any NetCDF-4 file, so that path is exercised against a test double of the
+//     library's C API only (tests/fake_libnetcdf.c) -- see INTEGRATION.md.
 //
 // Conventions kept from the reference loader:
 //   * the grid is taken from the first floating-point variable with 3 or 4 dimensions whose trailing dimensions are
@@ -53,19 +59,18 @@ private:
         std::string name;
         uint64_t length;  // 0 = the record (UNLIMITED) dimension
     };
-    struct Attr {
-        std::string name;
-        int type;
-        std::vector<unsigned char> raw;  // big-endian values
-        uint64_t nelems;
-    };
     struct Var {
         std::string name;
         std::vector<int> dimids;
-        std::vector<Attr> attrs;
-        int type;
-        uint64_t vsize, begin;
-        bool isRecord;
+        int type = 0;
+        // the attributes the loader acts on, extracted by whichever back end read the header
+        std::string standardName;
+        bool hasFill = false;
+        float fillValue = 0.0f;
+        // classic files: where the data lies; library back end: the variable id
+        uint64_t vsize = 0, begin = 0;
+        bool isRecord = false;
+        int varid = -1;
     };
     struct Field {
         std::string name;
@@ -74,8 +79,11 @@ private:
         float fillValue;
     };
 
+    struct Library;  // the netcdf-c entry points resolved with dlsym (NetCdfLoader.cpp)
     std::string path;
     mutable FILE* file = nullptr;
+    std::unique_ptr<Library> library;  // non-null: the file is open through netcdf-c (ncid below)
+    int ncid = -1;
     int version = 1;
     uint64_t numRecs = 0, recordSize = 0;
     std::vector<Dim> dims;
@@ -85,6 +93,9 @@ private:
     std::vector<std::string> warnings;
     int xs = 0, ys = 0, zs = 0, ts = 1, es = 1;
 
+    void parseClassicHeader();
+    void openWithLibrary(const char* why);
+    void deriveGridAndFields();
     uint64_t dimLength(int dimid) const;
     void readSlab(const Var& v, uint64_t leadingIndex, float* out) const;
     [[noreturn]] void error(const std::string& msg) const;

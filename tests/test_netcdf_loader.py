@@ -36,9 +36,60 @@ def _write(path, data, *, version=1, lead="member", names=("lev", "lat", "lon"),
     f.close()
 
 
-def _run(mode, path, out_dir):
-    r = subprocess.run([str(EXE), mode, str(path), str(out_dir)], capture_output=True, text=True, timeout=300)
+def _run(mode, path, out_dir, env=None):
+    import os
+    r = subprocess.run([str(EXE), mode, str(path), str(out_dir)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **(env or {})))
     return r
+
+
+@pytest.fixture(scope="module")
+def fake_netcdf(tmp_path_factory):
+    """The test double of netcdf-c's C API (tests/fake_libnetcdf.c) as a shared object for CRF_LIBNETCDF."""
+    out = tmp_path_factory.mktemp("fake") / "libnetcdf_fake.so"
+    src = Path(__file__).resolve().parent / "fake_libnetcdf.c"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", str(out), str(src)], check=True)
+    return out
+
+
+def _describe(path, dims, variables):
+    """Side-car description read by the test double: dims = [(name, len)], variables = [(name, type, dimids, opts, array)]."""
+    lines = ["dims %d %s" % (len(dims), " ".join(f"{n} {l}" for n, l in dims))]
+    for name, nctype, dimids, opts, arr in variables:
+        lines.append("var %s %d %d %s %s" % (name, nctype, len(dimids), " ".join(map(str, dimids)), " ".join(opts)))
+        lines.append(" ".join(repr(float(x)) for x in np.asarray(arr, np.float64).reshape(-1)))
+    Path(str(path) + ".fake").write_text("\n".join(lines) + "\n")
+
+
+def test_netcdf4_goes_through_the_netcdf_c_binding(tmp_path, fake_netcdf):
+    """An HDF5-signature file is handed to netcdf-c (dlopen of $CRF_LIBNETCDF): dimension conventions, standard_name,
+    fill value -> NaN, double -> float and the per-member hyperslab reads are the loader's; the library (here its test
+    double) only serves nc_* calls."""
+    rng = np.random.default_rng(8)
+    data = rng.standard_normal((4, 3, 2, 5))
+    data[2, 1, 0, 3] = -9999.0
+    other = rng.standard_normal((4, 3, 2, 5)).astype(np.float32)
+    path = tmp_path / "n4.nc"
+    path.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    _describe(path, [("members", 4), ("lev", 3), ("lat", 2), ("lon", 5)],
+              [("lon", 5, [3], [], np.arange(5)),
+               ("data", 6, [0, 1, 2, 3], ["standard_name=geopotential", "fill=-9999.0"], data),
+               ("other", 5, [0, 1, 2, 3], [], other)])
+    r = _run("netcdf", path, tmp_path, env={"CRF_LIBNETCDF": str(fake_netcdf)})
+    assert r.returncode == 0 and "NETCDF-OK" in r.stdout, r.stdout + r.stderr
+    meta = _parse(r.stdout)
+    assert meta["grid"] == (5, 2, 3) and meta["es"] == 4 and meta["ts"] == 1
+    assert meta["fields"] == ["geopotential", "other"] and not meta["warnings"]
+    want = data.astype(np.float32)
+    want[2, 1, 0, 3] = np.nan
+    for e in range(4):
+        np.testing.assert_array_equal(np.fromfile(tmp_path / f"geopotential_t0_e{e}.bin", np.float32), want[e].reshape(-1))
+        np.testing.assert_array_equal(np.fromfile(tmp_path / f"other_t0_e{e}.bin", np.float32), other[e].reshape(-1))
+    # a library without the expected entry points is reported as such
+    bad = tmp_path / "empty.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(bad), "-x", "c", "/dev/null"], check=True)
+    r = _run("netcdf", path, tmp_path, env={"CRF_LIBNETCDF": str(bad)})
+    assert r.returncode == 2 and "lacks the expected nc_* entry points" in r.stderr
 
 
 def _parse(stdout):
@@ -100,13 +151,14 @@ def test_unknown_leading_dimension_is_time_with_warning(tmp_path):
 
 
 def test_rejects_what_it_cannot_read(tmp_path):
+    # NetCDF-4 / CDF-5 without the netcdf-c library (this image has none): a message that says so and how to go on
     (tmp_path / "h.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    r = _run("netcdf", tmp_path / "h.nc", tmp_path)
-    assert r.returncode == 2 and "NetCDF-4" in r.stderr and "nccopy" in r.stderr
+    r = _run("netcdf", tmp_path / "h.nc", tmp_path, env={"CRF_LIBNETCDF": str(tmp_path / "no_such_lib.so")})
+    assert r.returncode == 2 and "NetCDF-4" in r.stderr and "nccopy" in r.stderr and "not found" in r.stderr
     (tmp_path / "c5.nc").write_bytes(b"CDF\x05" + b"\0" * 64)
     assert "CDF-5" in _run("netcdf", tmp_path / "c5.nc", tmp_path).stderr
     (tmp_path / "x.nc").write_bytes(b"not netcdf at all")
-    assert "not a NetCDF classic file" in _run("netcdf", tmp_path / "x.nc", tmp_path).stderr
+    assert "not a NetCDF file" in _run("netcdf", tmp_path / "x.nc", tmp_path).stderr
     good = tmp_path / "g.nc"
     _write(good, np.zeros((2, 2, 2, 2), np.float32))
     raw = good.read_bytes()
