@@ -7,7 +7,7 @@
 // Same mapping as the generic kernels (kernels_generic.hip): one lane = one voxel, the voxel's values in a per-lane
 // column [member][lane] of a tile in LDS (or, when it does not fit, in a global workspace slice owned by the persistent
 // block).  fp64 moments in member order exactly like the reference; the k-NN estimator sorts by counting (O(cs^2)
-// compares) and then runs the reference's step-halving window placement verbatim in fp32.  4*cs + 4 algorithmic bytes
+// compares) and then plays the reference's step-halving window descent (KnnWindow below) in fp32.  4*cs + 4 algorithmic bytes
 // per voxel; VALU/LDS bound.  fp64 log/exp come from the device math library (<= 1 ulp from the host's): results agree
 // with the CPU restatement to ~1e-15 before the cast to float (tolerance 1e-5 relative, tests/test_gpu_dkl.py).
 #include <cmath>
@@ -30,38 +30,37 @@ __host__ __device__ inline size_t dkl_tile_bytes(int cs, int estimator, int num_
 constexpr float kSglPi = 3.1415926535897932f;
 constexpr float kSglTwoPi = kSglPi * 2.0f;
 
-// findKNearestNeighbors<float> (DKL.cpp:98-130) on the lane's sorted column (stride 64)
+// Distance from sorted element i to its k-th nearest neighbour as the reference's heuristic finds it
+// (findKNearestNeighbors<float>, DKL.cpp:98-130): NOT an exact k-NN query but a descent over windows of k + 1 consecutive
+// sorted elements that hold element i, whose outcome -- including where it stalls -- is part of the estimator's
+// definition.  Restated here as a descent on a window COST: the window [lo, lo + k] costs the larger of the two gaps
+// from element i to its ends, an end that leaves the column or passes element i costs FLT_MAX.  Each round compares
+// the windows `step` to the left and to the right, moves towards the cheaper one unless the current window is
+// strictly cheaper than both, then halves the step (rounding up) until a round with step 1 has been played.  `col` is
+// the lane's ascending column (stride 64 floats).
+struct KnnWindow {
+    const float* col;
+    int n, k, i;
+    float centre;
+    __device__ float left_gap(int lo) const { return (lo >= 0 && lo <= i) ? centre - col[lo * 64] : 3.402823466e+38f; }
+    __device__ float right_gap(int hi) const { return (hi >= i && hi < n) ? col[hi * 64] - centre : 3.402823466e+38f; }
+    __device__ float cost(int lo) const { return fmaxf(left_gap(lo), right_gap(lo + k)); }
+};
+
 __device__ float dkl_window_distance(const float* data, int N, int k, int i) {
-    const float big = 3.402823466e+38f;
+    const KnnWindow w{data, N, k, i, data[i * 64]};
     int step = (k + 1) / 2;
-    int l = i - step > 0 ? i - step : 0;
-    int r = l + k;
-    if (r >= N) {
-        r = N - 1;
-        l = N - k - 1;
-    }
-    const float vc = data[i * 64];
+    // start: element i sits `step` from the left end, clamped into the column
+    int lo = i - step > 0 ? i - step : 0;
+    lo = lo + k >= N ? N - k - 1 : lo;
 #pragma unroll 1
-    while (true) {
-        const float vl = l >= 0 ? vc - data[l * 64] : big;
-        const float vr = r < N ? data[r * 64] - vc : big;
-        const float diff = (vl < vr) ? vr : vl;  // std::max(vl, vr)
-        const float vl0 = (l - step <= i && l - step >= 0) ? vc - data[(l - step) * 64] : big;
-        const float vr0 = (r - step >= i && r - step < N) ? data[(r - step) * 64] - vc : big;
-        const float diff0 = (vl0 < vr0) ? vr0 : vl0;
-        const float vl1 = (l + step <= i && l + step >= 0) ? vc - data[(l + step) * 64] : big;
-        const float vr1 = (r + step >= i && r + step < N) ? data[(r + step) * 64] - vc : big;
-        const float diff1 = (vl1 < vr1) ? vr1 : vl1;
-        const float d01 = diff0 - diff1;
-        int dir = d01 > 0.0f ? 1 : (d01 < 0.0f ? -1 : 0);
-        if (diff < diff0 && diff < diff1) dir = 0;
-        l += dir * step;
-        r += dir * step;
-        if (step == 1) break;
-        step = (step + 1) / 2;
+    for (bool last = false; !last; step = (step + 1) / 2) {
+        last = step == 1;
+        const float here = w.cost(lo), left = w.cost(lo - step), right = w.cost(lo + step);
+        const int towards = (left > right) - (left < right);  // +1: the right window is cheaper; 0: a draw
+        lo += (here < left && here < right) ? 0 : towards * step;
     }
-    const float a = vc - data[l * 64], b = data[r * 64] - vc;
-    return (a < b) ? b : a;
+    return w.cost(lo);
 }
 }  // namespace
 
