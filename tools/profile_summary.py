@@ -11,6 +11,10 @@ import os
 import statistics
 import sys
 from collections import defaultdict
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import kernel_source_sha256  # the hash bench.py checks before it reports a stored traffic figure
 
 
 def rows(pattern):
@@ -23,7 +27,7 @@ def short(name):
     name = name.split("(")[0]
     for key in ("pearson_reg_kernel", "pearson_stream_kernel", "pearson_prep_kernel", "spearman_kernel", "kendall_kernel",
                 "mi_binned_kernel", "mi_kraskov_kernel", "minmax_kernel", "synth_box_kernel", "gather_reference_kernel",
-                "fill_kernel"):
+                "spearman_split_kernel", "kendall_split_kernel", "direct_rank_kernel", "fill_kernel"):
         if key in name:
             return key
     return name[-60:]
@@ -66,7 +70,7 @@ def main():
             grid = [int(v) for v in argv[i + 1:i + 4]]
     traffic = pmc["FETCH_SIZE"].get(dominant, 0.0) * 1024 * 2 + pmc["WRITE_SIZE"].get(dominant, 0.0) * 1024
     entry = {f"{measure}:{grid[0]}x{grid[1]}x{grid[2]}x{members}:gpus1": {
-        "kernel": dominant, "traffic_bytes_per_launch": int(traffic),
+        "kernel": dominant, "traffic_bytes_per_launch": int(traffic), "source_sha256": kernel_source_sha256(measure),
         "fetch_kib_raw": pmc["FETCH_SIZE"].get(dominant), "write_kib": pmc["WRITE_SIZE"].get(dominant),
         "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B; calibrated: equals cs*M*4 exactly), "
                       "WRITE_SIZE x1; units KiB"}}
