@@ -120,9 +120,13 @@ __global__ __launch_bounds__(256) void kendall_prep_kernel(RefSource src, const 
 // ---------------------------------------------------------------------------------------------------------
 // Spearman
 // ---------------------------------------------------------------------------------------------------------
-// `todo` == nullptr: lane = voxel blockIdx*64+lane.  `todo` != nullptr: the kernel walks the list todo[1 .. 1+todo[0])
-// of voxel indices (voxels a fast kernel deferred because they contain ties) with a grid-stride loop.
-template <int N, bool EXACT, int MIN_WAVES>
+// LIST == false: lane = voxel blockIdx*64+lane, straight-line code.  LIST == true: the kernel walks the list
+// todo[1 .. 1+todo[0]) of voxel indices (voxels a fast kernel deferred because they contain ties) with a grid-stride loop.
+// Two instantiations rather than one kernel with an optional loop: inside a loop the compiler hoists the N member
+// buffer descriptors (4 SGPRs each) out of it as loop invariants, overflows the 102 SGPRs and parks them in VGPR lanes
+// -- 694 v_writelane / v_readlane around the 64 loads of the 64-member kernel, 15 % of its vector instructions, for a
+// loop that ran exactly once.
+template <int N, bool EXACT, int MIN_WAVES, bool LIST>
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* const* __restrict__ members,
                                                                  const float* __restrict__ prep,
                                                                  float* __restrict__ out, size_t num_voxels, int cs,
@@ -132,11 +136,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     constexpr int SURE = (N == 16) ? 8 : 0;
     const int lane = threadIdx.x;
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
-    const uint32_t count = todo ? todo[0] : 0u;
-    for (uint32_t base = blockIdx.x * 64u; todo == nullptr || base < count; base += gridDim.x * 64u) {
+    const uint32_t count = LIST ? todo[0] : 0u;
+    for (uint32_t base = blockIdx.x * 64u; !LIST || base < count; base += gridDim.x * 64u) {
     const uint32_t item = base + lane;
-    const bool active = todo ? item < count : item < num_voxels;
-    const size_t v = todo ? (active ? todo[1 + item] : num_voxels) : item;
+    const bool active = LIST ? item < count : item < num_voxels;
+    const size_t v = LIST ? (active ? todo[1 + item] : num_voxels) : item;
     const uint32_t byte_offset = uint32_t(v) * 4u;  // inactive lanes are out of range: they read 0 and store nothing
 
     composite_t a[N];
@@ -200,14 +204,14 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     float res = pearson_tail<N, EXACT, SURE>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) store_result_nt(out + v, res);
-    if (todo == nullptr) break;
+    if constexpr (!LIST) break;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Kendall
 // ---------------------------------------------------------------------------------------------------------
-template <int N, bool EXACT, int MIN_WAVES>
+template <int N, bool EXACT, int MIN_WAVES, bool LIST>  // LIST: see spearman_kernel
 __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* const* __restrict__ members,
                                                                 const int* __restrict__ prep, float* __restrict__ out,
                                                                 size_t num_voxels, int cs,
@@ -221,11 +225,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
         for (int i = lane; i < N; i += 64) gend_lds[i] = uint8_t(prep[N + i]);
         __syncthreads();
     }
-    const uint32_t count = todo ? todo[0] : 0u;
-    for (uint32_t base = blockIdx.x * 64u; todo == nullptr || base < count; base += gridDim.x * 64u) {
+    const uint32_t count = LIST ? todo[0] : 0u;
+    for (uint32_t base = blockIdx.x * 64u; !LIST || base < count; base += gridDim.x * 64u) {
     const uint32_t item = base + lane;
-    const bool active = todo ? item < count : item < num_voxels;
-    const size_t v = todo ? (active ? todo[1 + item] : num_voxels) : item;
+    const bool active = LIST ? item < count : item < num_voxels;
+    const size_t v = LIST ? (active ? todo[1 + item] : num_voxels) : item;
     const uint32_t byte_offset = uint32_t(v) * 4u;
 
     composite_t a[N];
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     float res = float(numerator) / denominator;
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) store_result_nt(out + v, res);
-    if (todo == nullptr) break;
+    if constexpr (!LIST) break;
     }
 }
 
@@ -573,24 +577,32 @@ template <int N, int MIN_WAVES>
 void launch_spearman_n(const float* const* d_members, const float* d_prep, float* d_out, size_t num_voxels, int cs,
                        hipStream_t s, const uint32_t* todo = nullptr) {
     const unsigned blocks = todo ? kTodoBlocks : unsigned((num_voxels + 63) / 64);
-    if (cs == N && env_exact())
-        hipLaunchKernelGGL((spearman_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs, todo);
-    else
-        hipLaunchKernelGGL((spearman_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs, todo);
+    const bool exact = cs == N && env_exact();
+#define CRF_LAUNCH_SPEARMAN(EX, LIST)                                                                                  \
+    hipLaunchKernelGGL((spearman_kernel<N, EX, MIN_WAVES, LIST>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out, \
+                       num_voxels, cs, todo)
+    if (todo) {
+        if (exact) CRF_LAUNCH_SPEARMAN(true, true); else CRF_LAUNCH_SPEARMAN(false, true);
+    } else {
+        if (exact) CRF_LAUNCH_SPEARMAN(true, false); else CRF_LAUNCH_SPEARMAN(false, false);
+    }
+#undef CRF_LAUNCH_SPEARMAN
 }
 
 template <int N, int MIN_WAVES>
 void launch_kendall_n(const float* const* d_members, const int* d_prep, float* d_out, size_t num_voxels, int cs,
                       hipStream_t s, const uint32_t* todo = nullptr) {
     const unsigned blocks = todo ? kTodoBlocks : unsigned((num_voxels + 63) / 64);
-    if (cs == N && env_exact())
-        hipLaunchKernelGGL((kendall_kernel<N, true, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs, todo);
-    else
-        hipLaunchKernelGGL((kendall_kernel<N, false, MIN_WAVES>), dim3(blocks), dim3(64), 0, s, d_members, d_prep,
-                           d_out, num_voxels, cs, todo);
+    const bool exact = cs == N && env_exact();
+#define CRF_LAUNCH_KENDALL(EX, LIST)                                                                                  \
+    hipLaunchKernelGGL((kendall_kernel<N, EX, MIN_WAVES, LIST>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out, \
+                       num_voxels, cs, todo)
+    if (todo) {
+        if (exact) CRF_LAUNCH_KENDALL(true, true); else CRF_LAUNCH_KENDALL(false, true);
+    } else {
+        if (exact) CRF_LAUNCH_KENDALL(true, false); else CRF_LAUNCH_KENDALL(false, false);
+    }
+#undef CRF_LAUNCH_KENDALL
 }
 
 // split-sort launchers: chunk A = CH members, chunk B sorted by a CHB-network (CH < cs <= CH + CHB)
