@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64) void binned_prep_kernel(RefSource src, const fl
 // LC: slots loaded per batch (N = all loads first; a smaller batch bounds the live values to N codes + LC samples, which
 // keeps the wide instantiations inside the 256 registers of two waves per SIMD -- 63 loads in flight is the hardware
 // limit anyway)
-template <int N, bool EXACT, int MIN_WAVES, int LC = N>
+// UDIV: the launcher found range = max_q - min_q inside [2^-60, 2^60] (see the comment at rcp_q below)
+template <int N, bool EXACT, int MIN_WAVES, int LC = N, bool UDIV = false>
 __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* const* __restrict__ members,
                                                                   const int* __restrict__ prep,
                                                                   const double* __restrict__ tableT,
@@ -96,6 +97,15 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
     int total = 0;
     const float range_q = max_q - min_q;
     const double nbd = double(nb);
+    // (y - min) / range with ONE true division per evaluation: range is the same for every sample, and with
+    // rcp = RN(1 / range) the quotient q = fma(fma(-q0, range, d), rcp, q0), q0 = RN(d * rcp), is the correctly rounded
+    // d / range (Markstein; crf_device.h: exact_div) whenever the remainder is exact.  Where it is not -- |d| < 2^-100,
+    // or a quotient that leaves the normal range -- the quotient is below 2^-40 or infinite either way and lands in the
+    // same bin (0) as the division's; for d = +-inf (or an overflowing q0) the chain yields NaN where the division
+    // yields +-inf: both convert to bin 0 (bin_index_x86), and whether the sample counts is decided from the sample
+    // itself (with finite min and range the division is NaN iff the sample is).  range outside [2^-60, 2^60] (incl. 0, NaN: max == min, infinite extrema) keeps the division:
+    // the launcher picks the instantiation (a branch per sample in the unrolled loop costs registers).
+    const float rcp_q = UDIV ? 1.0f / range_q : 0.0f;
     static_assert(N % LC == 0, "whole batches");
 #pragma unroll
     for (int base = 0; base < N; base += LC) {
@@ -113,9 +123,23 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
             const int e = base + i;
             const bool member = is_member(e);
             is_nan |= member && (y[i] != y[i]);
-            const float q01 = (y[i] - min_q) / range_q;  // CorrelationCalculator.cpp:1061-1062
-            const int b0 = prep[e];                      // pads: kInvalidBin (binned_prep_kernel)
-            const bool valid = member && (q01 == q01) && b0 != kInvalidBin;
+            const float d = y[i] - min_q;  // CorrelationCalculator.cpp:1061-1062
+            float q01;
+            bool not_nan;
+            if constexpr (UDIV) {
+                const float q0 = d * rcp_q;
+                q01 = fmaf(fmaf(-q0, range_q, d), rcp_q, q0);
+                not_nan = d == d;  // min and range are finite here: the division is NaN iff the sample (and so d) is
+            } else {
+                q01 = d / range_q;
+                not_nan = q01 == q01;
+            }
+            // reference bin of the member; kInvalidBin = 0xFFFF for a skipped reference sample (and for pads): OR-ed
+            // into the code it leaves the low 16 bits all ones, which IS the pad marker of the slow path below -- no
+            // per-member test needed here (64 uniform conditions held in SGPR pairs cost lane spills); such an
+            // evaluation has ref_all_valid == false and every lane recounts its samples on the slow path
+            const int b0 = prep[e];
+            const bool valid = member && not_nan;
             int b1 = bin_index_x86(double(q01) * nbd);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
             a[e] = valid ? (uint32_t(b1) << 8) | uint32_t(b0) : kPadCode;
@@ -164,8 +188,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
         // Samples were skipped: probabilities are c/total with total < cs.  Direct O(cs^2) evaluation over the
         // lane's LDS column; first occurrence of each bin/cell contributes its term.
         mi = 0.0;
-        if (total > 0) {
-            const double tot = double(total);
+        int counted = 0;  // samples with a query bin AND a reference bin
+#pragma unroll 1
+        for (int i = 0; i < cs; i++) counted += codes[i * 64 + lane] != 0xFFFFu;
+        if (counted > 0) {
+            const double tot = double(counted);
             const double eps1 = 0.5 / double(cs);
             const double eps2 = 0.5 / double(cs * cs);
 #pragma unroll 1
@@ -409,12 +436,18 @@ template <int N, int MIN_WAVES, int LC = N>
 void launch_binned_n(const float* const* d_members, const int* prep, const double* tableT, float* d_out,
                      size_t num_voxels, int cs, const BinnedArgs& a, hipStream_t s) {
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
-    if (cs == N)
-        hipLaunchKernelGGL((mi_binned_kernel<N, true, MIN_WAVES, LC>), dim3(blocks), dim3(64), 0, s, d_members, prep,
-                           tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
-    else
-        hipLaunchKernelGGL((mi_binned_kernel<N, false, MIN_WAVES, LC>), dim3(blocks), dim3(64), 0, s, d_members, prep,
-                           tableT, d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc));
+    const float range = a.max_query - a.min_query;  // the same fp32 subtraction the kernel performs
+    const char* plain = getenv("CRF_BINNED_PLAIN_DIV");  // tuning / tests: always the per-sample division
+    const bool udiv = range >= 0x1p-60f && range <= 0x1p60f && !(plain && *plain == '1');
+#define CRF_LAUNCH_BINNED(EX, UD)                                                                                      \
+    hipLaunchKernelGGL((mi_binned_kernel<N, EX, MIN_WAVES, LC, UD>), dim3(blocks), dim3(64), 0, s, d_members, prep, tableT, \
+                       d_out, num_voxels, cs, a.num_bins, a.min_query, a.max_query, int(a.to_cc))
+    if (cs == N) {
+        if (udiv) CRF_LAUNCH_BINNED(true, true); else CRF_LAUNCH_BINNED(true, false);
+    } else {
+        if (udiv) CRF_LAUNCH_BINNED(false, true); else CRF_LAUNCH_BINNED(false, false);
+    }
+#undef CRF_LAUNCH_BINNED
 }
 
 
