@@ -35,7 +35,9 @@ struct BinnedRequestArgs {
     int use_abs;
 };
 
-template <int N, bool EXACT, int MIN_WAVES, bool REQ = false>
+// UDIV (field mode): both ranges lie in [2^-60, 2^60] (the launcher checks): the per-sample division is formed from one
+// reciprocal per evaluation with the Markstein correction, exactly as in mi_binned_kernel (kernels_binned.hip: rcp_q)
+template <int N, bool EXACT, int MIN_WAVES, bool REQ = false, bool UDIV = false>
 __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const float* const* __restrict__ members_x,
                                                                          const float* const* __restrict__ members_y,
                                                                          const double* __restrict__ tableT,
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const auto is_member = [cs](int e) { return EXACT || e < SURE || e < cs; };
     const float range_x = ba.max_x - ba.min_x, range_y = ba.max_y - ba.min_y;
+    const float rcp_x = UDIV ? 1.0f / range_x : 0.0f, rcp_y = UDIV ? 1.0f / range_y : 0.0f;
     const double nbd = double(ba.num_bins);
     const int nb = ba.num_bins;
     uint32_t a[N];
@@ -106,10 +109,19 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
         for (int e = 0; e < N; e++) {
             const bool member = is_member(e);
             is_nan |= member && (x[e] != x[e]);
-            const float x01 = (x[e] - ba.min_x) / range_x;  // CorrelationCalculator.cpp:1061-1062
+            const float dx = x[e] - ba.min_x;  // CorrelationCalculator.cpp:1061-1062
+            float x01;
+            if constexpr (UDIV) {
+                const float q0 = dx * rcp_x;
+                x01 = fmaf(fmaf(-q0, range_x, dx), rcp_x, q0);
+            } else {
+                x01 = dx / range_x;
+            }
             int b0 = bin_index_x86(double(x01) * nbd);
             b0 = b0 < 0 ? 0 : (b0 > nb - 1 ? nb - 1 : b0);
-            a[e] = (member && x01 == x01) ? uint32_t(b0) : kPadCode;
+            // UDIV: with finite min and range the division is NaN iff the sample is (an infinite sample makes the fma
+            // chain NaN where the division gives inf: both fall into bin 0)
+            a[e] = (member && (UDIV ? dx == dx : x01 == x01)) ? uint32_t(b0) : kPadCode;
         }
         uint32_t nan_flag = is_nan ? 1u : 0u;  // pinned: otherwise the samples stay alive to the end (kernels_binned.hip)
         asm volatile("" : "+v"(nan_flag));
@@ -126,10 +138,17 @@ __global__ __launch_bounds__(64, MIN_WAVES) void binned_symmetric_kernel(const f
         for (int e = 0; e < N; e++) {
             const bool member = is_member(e);
             is_nan |= member && (y[e] != y[e]);
-            const float y01 = (y[e] - ba.min_y) / range_y;
+            const float dy = y[e] - ba.min_y;
+            float y01;
+            if constexpr (UDIV) {
+                const float q0 = dy * rcp_y;
+                y01 = fmaf(fmaf(-q0, range_y, dy), rcp_y, q0);
+            } else {
+                y01 = dy / range_y;
+            }
             int b1 = bin_index_x86(double(y01) * nbd);
             b1 = b1 < 0 ? 0 : (b1 > nb - 1 ? nb - 1 : b1);
-            const bool valid = member && (y01 == y01) && a[e] != kPadCode;
+            const bool valid = member && (UDIV ? dy == dy : y01 == y01) && a[e] != kPadCode;
             a[e] = valid ? (uint32_t(b1) << 8) | a[e] : kPadCode;
             total += valid ? 1 : 0;
         }
@@ -264,8 +283,15 @@ struct BinnedLauncher {
                 hipLaunchKernelGGL((binned_symmetric_kernel<N, false, RW, true>), grid, dim3(64), 0, s, mx, my, tableT,
                                    out, num_voxels, cs, ba, num_items, ra);
         } else {
-            hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES, false>), grid, dim3(64), 0, s, mx, my, tableT,
-                               out, num_voxels, cs, ba, num_items, ra);
+            const float rx = ba.max_x - ba.min_x, ry = ba.max_y - ba.min_y;  // the kernel's own fp32 subtractions
+            const char* plain = getenv("CRF_BINNED_PLAIN_DIV");              // tuning / tests
+            const bool udiv = rx >= 0x1p-60f && rx <= 0x1p60f && ry >= 0x1p-60f && ry <= 0x1p60f && !(plain && *plain == '1');
+            if (udiv)
+                hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES, false, true>), grid, dim3(64), 0, s, mx, my,
+                                   tableT, out, num_voxels, cs, ba, num_items, ra);
+            else
+                hipLaunchKernelGGL((binned_symmetric_kernel<N, EXACT, WAVES, false, false>), grid, dim3(64), 0, s, mx, my,
+                                   tableT, out, num_voxels, cs, ba, num_items, ra);
         }
     }
 };
