@@ -18,6 +18,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -80,6 +82,9 @@ std::string fmt(const char* f, ...) {
 thread_local std::string g_group_create_error;
 
 // One persistent thread per device: run(job) hands the same job to every worker and returns when all are done.
+// Hand-off in both directions first SPINS for a short while (evaluations of an interactive session follow each other
+// within milliseconds, and a futex wake-up out of an idle state costs 50-150 us each way -- measured 0.28 ms per
+// evaluation with plain condition variables) and only then sleeps on a condition variable.
 class Workers {
 public:
     explicit Workers(int n) : n_(n), status_(size_t(n), 0) {
@@ -89,7 +94,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
-            generation_++;
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         for (auto& t : threads_) t.join();
@@ -99,12 +104,14 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &job;
-            remaining_ = n_;
-            generation_++;
+            remaining_.store(n_, std::memory_order_relaxed);
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return remaining_ == 0; });
+        if (!spin_until([this] { return remaining_.load(std::memory_order_acquire) == 0; })) {
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait(lk, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
+        }
         job_ = nullptr;
         for (int s : status_)
             if (s) return s;
@@ -124,22 +131,35 @@ public:
     }
 
 private:
+    template <class Pred>
+    static bool spin_until(Pred done, double seconds = 300e-6) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; i++) {
+            if (done()) return true;
+            if ((i & 63) == 63 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+                return false;
+            std::this_thread::yield();
+        }
+    }
     void loop(int r) {
         unsigned long seen = 0;
         for (;;) {
+            if (!spin_until([&] { return generation_.load(std::memory_order_acquire) != seen; })) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+            }
             const std::function<int(int)>* job;
             {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return generation_ != seen; });
-                seen = generation_;
+                std::lock_guard<std::mutex> lk(m_);  // pairs with run(): job_ is published under the same lock
+                seen = generation_.load(std::memory_order_acquire);
                 if (stop_) return;
                 job = job_;
             }
             const int s = (*job)(r);
-            {
+            status_[size_t(r)] = s;
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m_);
-                status_[size_t(r)] = s;
-                if (--remaining_ == 0) done_cv_.notify_all();
+                done_cv_.notify_all();
             }
         }
     }
@@ -149,8 +169,10 @@ private:
     std::mutex m_, bm_;
     std::condition_variable cv_, done_cv_, bcv_;
     const std::function<int(int)>* job_ = nullptr;
-    unsigned long generation_ = 0, barrier_gen_ = 0;
-    int remaining_ = 0, arrived_ = 0;
+    std::atomic<unsigned long> generation_{0};
+    std::atomic<int> remaining_{0};
+    unsigned long barrier_gen_ = 0;
+    int arrived_ = 0;
     bool stop_ = false;
 };
 
@@ -427,7 +449,12 @@ int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
     const bool from_secondary = (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY) != 0;
     const bool use_rccl = !g->comms.empty();
     const bool single = g->n == 1 && !use_rccl;
+    const char* trace_env = getenv("CRF_GROUP_TRACE");  // development: host-side phase times of slot 0 on stderr
+    const bool trace = trace_env && *trace_env == '1';
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
     const int status = g->workers->run([&](int r) -> int {
+        const double t_start = since();
         crf_context* c = g->ctx[size_t(r)];
         if (hipSetDevice(g->ordinals[size_t(r)]) != hipSuccess) return CRF_ERR_DEVICE;
         crf_params local = *p;
@@ -460,8 +487,14 @@ int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
             dref = mine;
             if (rc != CRF_OK) return rc;
         }
-        return crf::compute_to_host(c, &local, dref, host_out + slice * size_t(g->z_begin[size_t(r)]));
+        const double t_exchanged = since();
+        const int rc2 = crf::compute_to_host(c, &local, dref, host_out + slice * size_t(g->z_begin[size_t(r)]));
+        if (trace && r == 0)
+            fprintf(stderr, "crf_group_compute slot 0: job started %.0f us after the call, exchange issued by %.0f us, done %.0f us\n",
+                    t_start, t_exchanged, since());
+        return rc2;
     });
+    if (trace) fprintf(stderr, "crf_group_compute: returned to the caller after %.0f us\n", since());
     return collect(g, status, "crf_group_compute");
 }
 
