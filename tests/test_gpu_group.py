@@ -114,3 +114,42 @@ def test_group_errors():
         grp.upload_members(np.zeros((4, 3, 4, 4), np.float32))
         with pytest.raises(ca.CorrFieldError, match="outside"):
             grp.compute(Measure.PEARSON, (0, 0, 3))
+
+
+def test_group_stress_many_evaluations_and_lifetimes(engine):
+    """Hand-off robustness: groups created and destroyed repeatedly, a few hundred evaluations with changing measures and
+    reference points (the workers alternate between spinning and sleeping), noise tables installed group-wide."""
+    xs, ys, zs, cs = 16, 8, 9, 16
+    ens = synth.box_ensemble(xs, ys, zs, cs, seed=13)
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    rng = np.random.default_rng(0)
+    for life in range(4):
+        with ca.CorrFieldGroup([0] * (2 + life % 2)) as grp:
+            grp.set_grid(xs, ys, zs, cs)
+            grp.upload_members(ens)
+            for it in range(60):
+                measure = ALL[int(rng.integers(0, len(ALL)))]
+                ref = (int(rng.integers(0, xs)), int(rng.integers(0, ys)), int(rng.integers(0, zs)))
+                got = grp.compute(measure, ref, k=2)
+                assert_bit_exact(got, engine.compute(measure, ref, k=2), f"stress life={life} it={it} {measure.name} {ref}")
+                if it == 30:
+                    import time
+                    time.sleep(0.01)       # long enough for the workers to fall asleep
+    # noise tables reach every slab
+    import ctypes as C
+    r = (np.arange(cs) * 1e-12).astype(np.float64)
+    q = (np.arange(cs)[::-1] * 1e-12).astype(np.float64)
+    with ca.CorrFieldGroup([0, 0]) as grp:
+        grp.set_grid(xs, ys, zs, cs)
+        grp.upload_members(ens)
+        rc = grp._lib.crf_group_set_kraskov_noise(grp._g, r.ctypes.data_as(C.POINTER(C.c_double)),
+                                                   q.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0
+        engine.set_kraskov_noise(r, q)
+        try:
+            ref = (4, 4, 4)
+            assert_bit_exact(grp.compute(Measure.MUTUAL_INFORMATION_KRASKOV, ref, k=3),
+                             engine.compute(Measure.MUTUAL_INFORMATION_KRASKOV, ref, k=3), "group noise tables")
+        finally:
+            engine.set_kraskov_noise(None)
