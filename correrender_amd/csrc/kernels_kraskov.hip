@@ -548,7 +548,14 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // The LDS-tile kernels below are instantiated for k <= 4 and hold a 256*cs-byte column per wave, which caps the
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
-    if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1')) {
+    // r02, with K = k instantiations of the tile-free kernel (256^3, tile vs tile-free, profiles/r02_kraskov_tile_vs_direct.txt):
+    //   k = 2: 4.0 / 11.1 / 19.3 / 33.2 / 47.4 / 60.5 ms vs 3.0 / 8.8 / 17.5 / 30.1 / 40.4 / 45.0 ms at 16 / 32 / 48 / 64 / 72 / 80 members
+    //   k = 3: 4.3 / 12.1 / 21.1 / 36.5 / 53.1 / 67.7 ms vs 3.6 / 10.6 / 21.0 / 35.9 / 48.4 / 53.9 ms
+    //   k = 1 and k = 4: the tile kernel wins below 64 members (k = 1: 14.8 vs 15.9 ms at 48), loses from 64 on (31.0 vs 27.1 ms)
+    const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
+    const bool prefer_direct = kk == 2 || kk == 3 || cs >= 64;
+    if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
+        (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
                                                 ev_end, info);
         if (e != hipErrorNotSupported) return e;
