@@ -20,6 +20,7 @@
 // compares against [c-r, c+r); psi(n) comes from a table.  The tie-breaking noise (1e-10 * u) uses this repo's
 // documented xorshift32 stream, identical to oracle/corr_oracle.cpp (sgl's generator is not available).
 #include <cstdlib>
+#include <type_traits>
 
 #include "crf_device.h"
 #include "crf_internal.h"
@@ -333,16 +334,23 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                     yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                     if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                 }
+                // A candidate past the end gets +inf coordinates (one uniform select per candidate, not one per pair;
+                // both coordinates: with only y = inf a point whose own y is +inf would see |inf - inf| = NaN and
+                // v_max_f64 would fall back to the finite x distance).  The point itself is masked by overwriting the
+                // HIGH dword of its distance with 0x7FEFFFFF -- a finite value beyond any real distance, whatever the
+                // low dword holds: one v_cndmask per pair instead of the two of a 64-bit select.
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
                     const int j = j0 + u;
                     const int jc = j < cs ? j : cs - 1;
-                    const double pxj = SYM ? double(xb[SYM ? u : 0]) + s_px[jc] : s_px[jc];
-                    const double pyj = double(yb[u]) + s_nq[jc];
+                    const double pxj = j < cs ? (SYM ? double(xb[SYM ? u : 0]) + s_px[jc] : s_px[jc]) : inf;
+                    const double pyj = j < cs ? double(yb[u]) + s_nq[jc] : inf;
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
                         double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
-                        d = (j == i0 + t || j >= cs) ? inf : d;
+                        const uint64_t bits = uint64_t(__double_as_longlong(d));
+                        const uint32_t hi = (j == i0 + t) ? 0x7FEFFFFFu : uint32_t(bits >> 32);
+                        d = __longlong_as_double((long long)((uint64_t(hi) << 32) | uint32_t(bits)));
 #pragma unroll
                         for (int q = 0; q < K; q++) {
                             const double lo = min_f64(best[t][q], d);
@@ -407,13 +415,15 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
                     const int jc = j0 + u < cs ? j0 + u : cs - 1;
-                    const double pyj = double(yb[u]) + s_nq[jc];
+                    // a candidate past the end is +inf: inside no [lo, hi) (hi is finite unless the voxel holds an
+                    // infinity, and then the result is NaN or decided by the NaN flag anyway -- see below)
+                    const double pyj = j0 + u < cs ? double(yb[u]) + s_nq[jc] : inf;
 #pragma unroll
-                    for (int t = 0; t < TI; t++) cy[t] += (j0 + u < cs && pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
+                    for (int t = 0; t < TI; t++) cy[t] += (pyj >= loy[t] && pyj < hiy[t]) ? 1 : 0;
                     if constexpr (SYM) {
-                        const double pxj = double(xb[u]) + s_px[jc];
+                        const double pxj = j0 + u < cs ? double(xb[u]) + s_px[jc] : inf;
 #pragma unroll
-                        for (int t = 0; t < TI; t++) cx[t] += (j0 + u < cs && pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
+                        for (int t = 0; t < TI; t++) cx[t] += (pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
                     }
                 }
             }
