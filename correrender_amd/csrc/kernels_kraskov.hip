@@ -558,12 +558,15 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // The LDS-tile kernels below are instantiated for k <= 4 and hold a 256*cs-byte column per wave, which caps the
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
-    // r02, with K = k instantiations of the tile-free kernel (256^3, tile vs tile-free, profiles/r02_kraskov_tile_vs_direct.txt):
-    //   k = 2: 4.0 / 11.1 / 19.3 / 33.2 / 47.4 / 60.5 ms vs 3.0 / 8.8 / 17.5 / 30.1 / 40.4 / 45.0 ms at 16 / 32 / 48 / 64 / 72 / 80 members
-    //   k = 3: 4.3 / 12.1 / 21.1 / 36.5 / 53.1 / 67.7 ms vs 3.6 / 10.6 / 21.0 / 35.9 / 48.4 / 53.9 ms
-    //   k = 1 and k = 4: the tile kernel wins below 64 members (k = 1: 14.8 vs 15.9 ms at 48), loses from 64 on (31.0 vs 27.1 ms)
+    // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 56 members the
+    // LDS-column kernel with 8 points per sweep wins (its column is small enough for three waves per SIMD): k = 3 at 32 /
+    // 48 members 9.1 / 18.7 ms vs 10.6 / 21.0 ms tile-free.  At 57..64 members the column allows two waves; k = 3 is a
+    // tie (36.7 vs 35.4 ms) and stays on the tile kernel, whose HBM traffic equals the algorithmic bytes (the tile-free
+    // kernel re-reads the members 16 times through L2 / the Infinity Cache: 47.9 GB at the fabric counters for 4.36 GB);
+    // k = 1 and k = 2 take the tile-free kernel (27.1 vs 31.0 ms, 27.9 vs 33.4 ms).  From 65 members on the tile-free
+    // kernel wins for every k (80 members, k = 3: 52.7 vs 67.7 ms).
     const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
-    const bool prefer_direct = kk == 2 || kk == 3 || cs >= 64;
+    const bool prefer_direct = cs > 64 || (cs > 56 && (kk == 1 || kk == 2));
     if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
         (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
@@ -579,7 +582,9 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
     const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    const bool wide = cs % 16 == 0 || cs % 16 > 8;
+    // 16 points per sweep only where the column caps the occupancy at two waves per SIMD anyway (more than 56 members)
+    const char* narrow = getenv("CRF_KRASKOV_TI8");  // tuning: 8 points per sweep for every member count
+    const bool wide = cs > 56 && (cs % 16 == 0 || cs % 16 > 8) && !(narrow && *narrow == '1');
 #define CRF_LAUNCH_KRASKOV(K, TI)                                                                                     \
     hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
                        d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)

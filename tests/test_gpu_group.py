@@ -18,9 +18,9 @@ ALL = [Measure.PEARSON, Measure.SPEARMAN, Measure.KENDALL, Measure.MUTUAL_INFORM
        Measure.MUTUAL_INFORMATION_KRASKOV, Measure.BINNED_MI_CORRELATION_COEFFICIENT, Measure.KMI_CORRELATION_COEFFICIENT]
 
 
-@pytest.mark.parametrize("slots", [2, 3])
+@pytest.mark.parametrize("slots", [2, 3, 8])
 def test_group_equals_single_context_all_measures(engine, slots):
-    xs, ys, zs, cs = 24, 10, 11, 32           # 11 slices over 2 / 3 slabs: uneven
+    xs, ys, zs, cs = 24, 10, 11, 32           # 11 slices over 2 / 3 / 8 slabs: uneven (8: the shape of BASELINE configs[4])
     ens = synth.box_ensemble(xs, ys, zs, cs, seed=5)
     engine.set_grid(xs, ys, zs, cs)
     engine.upload_members(ens)
