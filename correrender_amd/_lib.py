@@ -97,6 +97,7 @@ SYMBOLS = {
     "crf_group_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_group_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_group_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
+    "crf_group_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(_VOIDP)]),
     "crf_group_set_profiling": (C.c_int, [_VOIDP, C.c_int]),
     "crf_group_take_kernel_time": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -426,11 +426,16 @@ int crf_group_take_kernel_time(crf_group* g, double* out_ms_max, int* out_launch
     return CRF_OK;
 }
 
-// One evaluation over the whole grid into the caller's host buffer (xs*ys*zs floats): calculateCpu(t, e, buffer).
-int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
-    if (!g || !p || !host_out) return gfail(g, CRF_ERR_ARGUMENT, "null argument");
+// One evaluation over the whole grid: exchange of the reference vector, then every device evaluates its slab -- into its
+// part of the caller's HOST buffer (host_out != null: calculateCpu(t, e, buffer)) or into the caller's per-device DEVICE
+// buffers (device_outs[slot] receives the slab of that slot: xs*ys*z_count floats, resident for a device-side consumer).
+static int group_compute(crf_group* g, const crf_params* p, float* host_out, void* const* device_outs) {
+    if (!g || !p || (!host_out && !device_outs)) return gfail(g, CRF_ERR_ARGUMENT, "null argument");
     if (g->cs <= 0) return gfail(g, CRF_ERR_STATE, "crf_group_set_grid has not been called");
     if (p->prepared_slot != 0) return gfail(g, CRF_ERR_ARGUMENT, "prepared slots are per context, not per group");
+    if (device_outs)
+        for (int r = 0; r < g->n; r++)
+            if (!device_outs[r]) return gfail(g, CRF_ERR_ARGUMENT, fmt("device output of slot %d is a null pointer", r));
     const bool symmetric = (p->flags & CRF_FLAG_SYMMETRIC) != 0;
     const bool host_vector = p->reference_values != nullptr;
     const bool needs_exchange = !symmetric && !host_vector;
@@ -488,14 +493,33 @@ int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
             if (rc != CRF_OK) return rc;
         }
         const double t_exchanged = since();
-        const int rc2 = crf::compute_to_host(c, &local, dref, host_out + slice * size_t(g->z_begin[size_t(r)]));
+        int rc2;
+        if (host_out) {
+            rc2 = crf::compute_to_host(c, &local, dref, host_out + slice * size_t(g->z_begin[size_t(r)]));
+        } else {
+            rc2 = crf_compute_device(c, &local, dref, device_outs[r], nullptr);
+            if (rc2 == CRF_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+                c->err = "hipStreamSynchronize failed after the evaluation";
+                rc2 = CRF_ERR_DEVICE;
+            }
+        }
         if (trace && r == 0)
             fprintf(stderr, "crf_group_compute slot 0: job started %.0f us after the call, exchange issued by %.0f us, done %.0f us\n",
                     t_start, t_exchanged, since());
         return rc2;
     });
     if (trace) fprintf(stderr, "crf_group_compute: returned to the caller after %.0f us\n", since());
-    return collect(g, status, "crf_group_compute");
+    return collect(g, status, host_out ? "crf_group_compute" : "crf_group_compute_device");
+}
+
+int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
+    if (!host_out) return gfail(g, CRF_ERR_ARGUMENT, "null output");
+    return group_compute(g, p, host_out, nullptr);
+}
+
+int crf_group_compute_device(crf_group* g, const crf_params* p, void* const* device_outs) {
+    if (!device_outs) return gfail(g, CRF_ERR_ARGUMENT, "null output table");
+    return group_compute(g, p, nullptr, device_outs);
 }
 
 }  // extern "C"

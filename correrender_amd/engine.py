@@ -461,6 +461,26 @@ class CorrFieldGroup:
         del keep
         return out
 
+    def compute_device(self, measure, outs, ref=None, *, k=None, kraskov_estimator_index=1, num_bins=80, minmax_ref=None,
+                       minmax_query=None, reference_values=None, symmetric=False, reference_from_secondary=False,
+                       absolute_value=False):
+        """crf_group_compute_device: outs[slot] is a CUDA float32 tensor on the slot's device holding xs*ys*z_count
+        elements (slab(slot)); returns when every device has finished."""
+        flags, mode = CorrField._mode_flags(symmetric, reference_from_secondary, absolute_value)
+        minmax_ref, minmax_query = CorrField._binned_ranges(self, measure, minmax_ref, minmax_query, mode)
+        p, keep = CorrField._params(self, measure, ref, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query,
+                                    reference_values, flags)
+        xs, ys, _ = self.grid
+        if len(outs) != len(self.devices):
+            raise ValueError("one output tensor per device slot")
+        for slot, t in enumerate(outs):
+            if not t.is_cuda or not t.is_contiguous() or t.element_size() != 4 or t.numel() != xs * ys * self.slab(slot)[1]:
+                raise ValueError(f"output of slot {slot} must be a contiguous CUDA float32 tensor of the slab's size")
+        ptrs = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        self._check(self._lib.crf_group_compute_device(self._g, C.byref(p), ptrs))
+        del keep
+        return outs
+
     def set_profiling(self, enabled: bool):
         self._check(self._lib.crf_group_set_profiling(self._g, 1 if enabled else 0))
 

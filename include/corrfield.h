@@ -218,6 +218,10 @@ int crf_group_secondary_member_minmax(crf_group* group, float* out_min, float* o
  * host_out receives xs*ys*zs floats.  Supports the reference point, a host reference vector (no exchange),
  * CRF_FLAG_REFERENCE_FROM_SECONDARY, CRF_FLAG_SYMMETRIC (no exchange) and CRF_FLAG_ABSOLUTE_VALUE. */
 int crf_group_compute(crf_group* group, const crf_params* params, float* host_out);
+/* The same evaluation with DEVICE-resident results (what crf_compute_device is to crf_compute): device_outs[slot] is a
+ * buffer on the device of that slot and receives the slot's slab, xs*ys*z_count floats (crf_group_slab); returns when
+ * every device has finished.  For consumers that keep the field on the GPUs. */
+int crf_group_compute_device(crf_group* group, const crf_params* params, void* const* device_outs);
 int crf_group_set_profiling(crf_group* group, int enabled);
 /* Slowest device's summed kernel time (ms) and its launch count since the last call. */
 int crf_group_take_kernel_time(crf_group* group, double* out_ms_max, int* out_launches);

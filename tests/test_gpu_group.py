@@ -153,3 +153,23 @@ def test_group_stress_many_evaluations_and_lifetimes(engine):
                              engine.compute(Measure.MUTUAL_INFORMATION_KRASKOV, ref, k=3), "group noise tables")
         finally:
             engine.set_kraskov_noise(None)
+
+
+def test_group_device_resident_results(engine):
+    """crf_group_compute_device: every slot's slab stays on its device; concatenated they equal the single-context field."""
+    import torch
+    xs, ys, zs, cs = 20, 12, 10, 24
+    ens = synth.box_ensemble(xs, ys, zs, cs, seed=4)
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    with ca.CorrFieldGroup([0, 0, 0]) as grp:
+        grp.set_grid(xs, ys, zs, cs)
+        grp.upload_members(ens)
+        outs = [torch.empty(xs * ys * grp.slab(s)[1], dtype=torch.float32, device="cuda") for s in range(3)]
+        for measure in (Measure.PEARSON, Measure.KENDALL, Measure.MUTUAL_INFORMATION_BINNED):
+            for ref in [(1, 2, 0), (19, 11, 9)]:
+                grp.compute_device(measure, outs, ref)
+                got = torch.cat(outs).cpu().numpy()
+                assert_bit_exact(got, engine.compute(measure, ref), f"group device outputs {measure.name} {ref}")
+        with pytest.raises(ValueError):
+            grp.compute_device(Measure.PEARSON, outs[:2], (0, 0, 0))

@@ -55,8 +55,13 @@ def main():
             grp.upload_members(ens)
             m, lo = run(lambda p: grp.compute(measure, p, out=out, **kw))
             same = bool((grp.compute(measure, pts[-1], **kw).view(np.uint32) == want.view(np.uint32)).all())
+            import torch
+            outs = [torch.empty(xs * ys * grp.slab(s)[1], dtype=torch.float32, device=f"cuda:{d}")
+                    for s, d in enumerate(devices)]
+            md, lod = run(lambda p: grp.compute_device(measure, outs, p, **kw))
             print(json.dumps({"path": f"crf_group over devices {devices}", "exchange": grp.exchange, "ms_median": m,
-                              "ms_min": lo, "bit_identical_to_single_context": same}), flush=True)
+                              "ms_min": lo, "device_resident_ms_median": md, "device_resident_ms_min": lod,
+                              "bit_identical_to_single_context": same}), flush=True)
 
 
 if __name__ == "__main__":
