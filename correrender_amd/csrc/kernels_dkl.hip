@@ -10,7 +10,9 @@
 // compares) and then plays the reference's step-halving window descent (KnnWindow below) in fp32.  4*cs + 4 algorithmic bytes
 // per voxel; VALU/LDS bound.  fp64 log/exp come from the device math library (<= 1 ulp from the host's): results agree
 // with the CPU restatement to ~1e-15 before the cast to float (tolerance 1e-5 relative, tests/test_gpu_dkl.py).
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "crf_device.h"
 #include "crf_internal.h"
@@ -21,14 +23,39 @@ namespace {
 constexpr int kDklBlocks = 1024;
 constexpr size_t kDklLdsLimit = 60 * 1024;
 
-__host__ __device__ inline size_t dkl_tile_bytes(int cs, int estimator, int num_bins) {
+// ln(h) for the h = 0..cs samples a bin can hold (binned estimator), rounded up to 16 bytes; 0 for the k-NN estimator
+__host__ __device__ inline size_t dkl_log_table_bytes(int cs, int estimator) {
+    return estimator == 0 ? ((size_t(cs) + 1) * sizeof(double) + 15) & ~size_t(15) : 0;
+}
+
+// in_place: the k-NN estimator's network sort holds the whole column in registers and writes the sorted values back
+// over it -- one column instead of two (twice the resident blocks per CU for this latency-bound kernel)
+__host__ __device__ inline size_t dkl_tile_bytes(int cs, int estimator, int num_bins, bool in_place = false) {
     const size_t column = size_t(cs) * 64 * sizeof(float);
-    return estimator == 0 ? column + size_t(num_bins) * 64 * sizeof(uint16_t) : 2 * column;
+    return estimator == 0 ? column + size_t(num_bins) * 64 * sizeof(uint16_t) : (in_place ? column : 2 * column);
 }
 
 // sgl's Math.hpp declares PI and TWO_PI as float (see oracle/corr_oracle.cpp for the pinning note)
 constexpr float kSglPi = 3.1415926535897932f;
 constexpr float kSglTwoPi = kSglPi * 2.0f;
+
+// Sorts the lane's column (stride 64 floats, cs <= N values) into `sorted` with the N-input min/max network: keys that
+// order like the floats (crf_device.h: orderable_key), pads = 0xFFFFFFFF behind every real value, keys mapped back.
+template <int N>
+__device__ __forceinline__ void sort_column(const float* vals, float* sorted, int cs) {
+    uint32_t a[N];
+#pragma unroll
+    for (int e = 0; e < N; e++) a[e] = e < cs ? orderable_key(vals[(e < cs ? e : 0) * 64]) : 0xFFFFFFFFu;
+    __builtin_amdgcn_sched_barrier(0);  // the network is straight-line code: left to the scheduler it is interleaved
+    SortNet32<N>::sort(a);              // with the loads and stores around it and runs out of registers
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        const uint32_t key = a[p];
+        const uint32_t bits = (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key;
+        if (p < cs) sorted[p * 64] = __uint_as_float(bits);
+    }
+}
 
 // Distance from sorted element i to its k-th nearest neighbour as the reference's heuristic finds it
 // (findKNearestNeighbors<float>, DKL.cpp:98-130): NOT an exact k-NN query but a descent over windows of k + 1 consecutive
@@ -72,15 +99,30 @@ size_t dkl_workspace_bytes(int cs, int estimator, int num_bins, size_t num_voxel
 }
 
 // knn_const = psi(cs) - psi(k) + ln 2, half_log_two_pi = 0.5 * double(std::log(float TWO_PI)): host libm, fp64
-__global__ __launch_bounds__(64) void dkl_kernel(const float* const* __restrict__ members, float* __restrict__ out,
+// NS: size of the sorting network of the k-NN estimator's column sort (a multiple of 16 >= cs, at most 128), or 0: sort by
+// counting (any member count; also the instantiation the binned estimator runs).  One kernel per network size -- all
+// eight networks inside one kernel cost 512 registers and scratch.
+template <int NS>
+__global__ __launch_bounds__(64, (NS > 0 && NS <= 64) ? 2 : 1) void dkl_kernel(const float* const* __restrict__ members, float* __restrict__ out,
                                                  size_t num_voxels, int cs, int estimator, int num_bins, int k,
                                                  double knn_const, double half_log_two_pi,
                                                  unsigned char* __restrict__ workspace) {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* tile = workspace ? workspace + size_t(blockIdx.x) * dkl_tile_bytes(cs, estimator, num_bins) : smem;
+    // LDS: [ln(h), h = 0..cs, of the binned estimator (dkl_log_table_bytes)] [the tile, unless it lives in the workspace]
+    double* s_logn = reinterpret_cast<double*>(smem);
+    unsigned char* lds_tile = smem + dkl_log_table_bytes(cs, estimator);
+    // the network instantiations are only launched with the tile in LDS: with a plain LDS pointer the column accesses
+    // become ds_read / ds_write with immediate offsets; through the generic pointer of the workspace fallback the
+    // compiler materialises (and, the tile loop being persistent, hoists) one 64-bit address per column slot
+    unsigned char* tile = (NS > 0 || !workspace) ? lds_tile : workspace + size_t(blockIdx.x) * dkl_tile_bytes(cs, estimator, num_bins);
+    constexpr bool kInPlace = NS > 0;  // network sort: `sorted` is the value column itself
     const int lane = threadIdx.x;
+    if (estimator == 0) {
+        for (int h = lane; h <= cs; h += 64) s_logn[h] = h > 0 ? log(double(h)) : 0.0;
+        __syncthreads();
+    }
     float* vals = reinterpret_cast<float*>(tile) + lane;
-    float* sorted = vals + size_t(cs) * 64;                                                    // k-NN
+    float* sorted = kInPlace ? vals : vals + size_t(cs) * 64;                                  // k-NN
     uint16_t* hist = reinterpret_cast<uint16_t*>(tile + size_t(cs) * 64 * sizeof(float)) + lane;  // binned
     const uint32_t bytes = uint32_t(num_voxels) * 4u;
     const size_t tiles = (num_voxels + 63) / 64;
@@ -107,12 +149,26 @@ __global__ __launch_bounds__(64) void dkl_kernel(const float* const* __restrict_
             variance += factor * diff * diff;
         }
         const double stdev = sqrt(variance);
+        // (v - mean) / stdev for the cs members of the voxel: ONE division (the reciprocal) per voxel, the quotients
+        // from q0 = RN(a * rcp), q = fma(fma(-q0, stdev, a), rcp, q0) -- the correctly rounded a / stdev (Markstein)
+        // whenever the remainder is exact, which a standard deviation in [2^-400, 2^400] guarantees for every
+        // deviation that is 0 or not below 2^-500; everything else (incl. stdev = 0: a constant voxel) divides.
+        const bool by_reciprocal = __all(stdev >= 0x1p-400 && stdev <= 0x1p400);
+        const double rcp_sd = 1.0 / stdev;
+        auto normalised = [&](double a) {
+            if (by_reciprocal) {
+                const double q0 = a * rcp_sd;
+                const double q = fma(fma(-q0, stdev, a), rcp_sd, q0);
+                return (fabs(a) >= 0x1p-500 || a == 0.0) ? q : a / stdev;
+            }
+            return a / stdev;
+        };
         float res;
         if (estimator == 0) {
             double min_val = 1.7976931348623157e308, max_val = -1.7976931348623157e308;
 #pragma unroll 2
             for (int e = 0; e < cs; e++) {
-                const double val = (double(vals[e * 64]) - mean) / stdev;
+                const double val = normalised(double(vals[e * 64]) - mean);
                 vals[e * 64] = float(val);
                 min_val = (val < min_val) ? val : min_val;  // std::min / std::max: a NaN never replaces the extremum
                 max_val = (max_val < val) ? val : max_val;
@@ -131,37 +187,52 @@ __global__ __launch_bounds__(64) void dkl_kernel(const float* const* __restrict_
                 b = b < 0 ? 0 : (b > num_bins - 1 ? num_bins - 1 : b);
                 hist[b * 64] = uint16_t(hist[b * 64] + 1u);
             }
+            // ln(px * binFactor / (gaussNorm * exp(-c^2 / 2))) = ln(h) + ln(binFactor / (cs * gaussNorm)) + c^2 / 2: one
+            // logarithm per voxel and a table of ln(h) instead of a logarithm, an exponential and a division per
+            // occupied bin (the reference's form, DKL.cpp:70-78; agreement ~1e-15 relative before the cast to float).
+            // Its exp underflows to 0 beyond c^2 / 2 = 745.13..., the quotient becomes inf and the result NaN (:80-82):
+            // kept as an explicit test.
             const double gauss_norm = sqrt(0.5 / double(kSglPi));
+            const double log_scale = log(bin_factor / (double(cs) * gauss_norm));
             double dkl = 0.0;
+            bool overflow = false;
 #pragma unroll 1
             for (int b = 0; b < num_bins; b++) {
                 const uint32_t h = hist[b * 64];
                 if (h > 0u) {
                     const double px = double(h) / double(cs);
                     const double center = (double(b) + 0.5) * bin_factor_inv + min_val;
-                    dkl += log(px * bin_factor / (gauss_norm * exp(-0.5 * (center * center)))) * px;
+                    const double half_sq = 0.5 * (center * center);
+                    overflow |= half_sq > 745.1332191019411;
+                    dkl += (s_logn[h] + log_scale + half_sq) * px;
                 }
             }
-            res = isinf(dkl) ? qnan : float(dkl);
+            res = (overflow || isinf(dkl)) ? qnan : float(dkl);
         } else {
             bool any_nan = false;
 #pragma unroll 2
             for (int e = 0; e < cs; e++) {
-                const float val = float((double(vals[e * 64]) - mean) / stdev);
+                const float val = float(normalised(double(vals[e * 64]) - mean));
                 any_nan |= val != val;
                 vals[e * 64] = val;
             }
-            // ascending sort by counting: position = #{smaller} + #{equal with a lower index}
+            // ascending sort of the lane's column: up to 128 members through a register min/max network on
+            // order-preserving 32-bit keys (r02; the estimator only reads the sorted VALUES, so the order among equal
+            // values is immaterial; with a NaN the result is NaN whatever the column holds), beyond that by counting
+            if constexpr (NS > 0) {
+                sort_column<NS>(vals, sorted, cs);
+            } else {
 #pragma unroll 1
-            for (int e = 0; e < cs; e++) {
-                const float ve = vals[e * 64];
-                int pos = 0;
+                for (int e = 0; e < cs; e++) {  // position = #{smaller} + #{equal with a lower index}
+                    const float ve = vals[e * 64];
+                    int pos = 0;
 #pragma unroll 4
-                for (int j = 0; j < cs; j++) {
-                    const float vj = vals[j * 64];
-                    pos += (vj < ve || (vj == ve && j < e)) ? 1 : 0;
+                    for (int j = 0; j < cs; j++) {
+                        const float vj = vals[j * 64];
+                        pos += (vj < ve || (vj == ve && j < e)) ? 1 : 0;
+                    }
+                    sorted[(any_nan ? e : pos) * 64] = ve;
                 }
-                sorted[(any_nan ? e : pos) * 64] = ve;
             }
             double entropy = 0.0, second_moment = 0.0;
 #pragma unroll 1
@@ -186,14 +257,51 @@ hipError_t launch_dkl(const float* const* d_members, int cs, size_t num_voxels, 
                       double knn_const, unsigned char* d_workspace, float* d_out, hipStream_t s, hipEvent_t ev_begin,
                       hipEvent_t ev_end, LaunchInfo* info) {
     const size_t tiles = (num_voxels + 63) / 64;
-    const unsigned blocks = unsigned(tiles < size_t(kDklBlocks) ? tiles : size_t(kDklBlocks));
-    const size_t tile = dkl_tile_bytes(cs, estimator, num_bins);
-    const bool use_lds = tile <= kDklLdsLimit;
+    unsigned blocks = unsigned(tiles < size_t(kDklBlocks) ? tiles : size_t(kDklBlocks));
+    const char* counting = getenv("CRF_DKL_COUNTING_SORT");  // tuning / tests: the O(cs^2) column sort for every cs
+    const bool network_sort = estimator == 1 && cs <= 128 && !(counting && *counting == '1');
+    const size_t tile = dkl_tile_bytes(cs, estimator, num_bins, network_sort);
+    const bool use_lds = tile <= kDklLdsLimit;  // (one column of <= 128 members always fits)
     if (!use_lds && !d_workspace) return hipErrorInvalidValue;
+    const size_t lds_bytes = dkl_log_table_bytes(cs, estimator) + (use_lds ? tile : 0);
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    hipLaunchKernelGGL(dkl_kernel, dim3(blocks), dim3(64), use_lds ? tile : 0, s, d_members, d_out, num_voxels, cs,
-                       estimator, num_bins, k, knn_const, 0.5 * double(std::log(kSglTwoPi)),
-                       use_lds ? nullptr : d_workspace);
+    // persistent grid = the blocks the chip holds at once, asked from the runtime per instantiation (registers and the
+    // LDS tile decide; a grid one block per CU larger than that runs a second round: measured 13.9 -> 18.5 ms)
+#define CRF_LAUNCH_DKL(NS)                                                                                              \
+    if (use_lds) {                                                                                                      \
+        int per_cu = 0, cus = 256;                                                                                      \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dkl_kernel<NS>, 64, lds_bytes) == hipSuccess &&      \
+            per_cu > 0) {                                                                                               \
+            /* the runtime's answer was one block high for both estimators (LDS is handed out in 1280-byte granules:  \
+               160 KB / 128); a grid one block per CU too large runs a second round: 11.1 -> 18.6 ms (binned), 17.5 -> \
+               31.0 ms (k-NN, two columns) */                                                                          \
+            const size_t granules = (lds_bytes + 1279) / 1280;                                                          \
+            const int by_lds = granules ? int(128 / granules) : per_cu;                                                 \
+            per_cu = std::max(1, std::min(per_cu, by_lds));                                                             \
+            int dev = 0;                                                                                                \
+            (void)hipGetDevice(&dev);                                                                                   \
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);                              \
+            if (const char* ov = getenv("CRF_DKL_BLOCKS_PER_CU"); ov && atoi(ov) > 0) per_cu = atoi(ov); /* tuning */    \
+            const size_t resident = size_t(cus > 0 ? cus : 256) * size_t(per_cu);                                       \
+            blocks = unsigned(tiles < resident ? tiles : resident);                                                     \
+        }                                                                                                               \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(dkl_kernel<NS>, dim3(blocks), dim3(64), lds_bytes, s, d_members, d_out, num_voxels, cs,      \
+                       estimator, num_bins, k, knn_const, 0.5 * double(std::log(kSglTwoPi)),                              \
+                       use_lds ? nullptr : d_workspace)
+    const int network = network_sort ? (cs + 15) / 16 : 0;
+    switch (network) {
+        case 1: CRF_LAUNCH_DKL(16); break;
+        case 2: CRF_LAUNCH_DKL(32); break;
+        case 3: CRF_LAUNCH_DKL(48); break;
+        case 4: CRF_LAUNCH_DKL(64); break;
+        case 5: CRF_LAUNCH_DKL(80); break;
+        case 6: CRF_LAUNCH_DKL(96); break;
+        case 7: CRF_LAUNCH_DKL(112); break;
+        case 8: CRF_LAUNCH_DKL(128); break;
+        default: CRF_LAUNCH_DKL(0); break;
+    }
+#undef CRF_LAUNCH_DKL
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "dkl_kernel";
     return hipGetLastError();
