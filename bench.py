@@ -284,7 +284,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms,
             "ms_per_step": ms_per_step, "ms_per_step_min": stats["min"], "ms_per_step_max": stats["max"],
             "timed_blocks": stats["blocks"], "host_issue_ms_per_step": round(issue_ms, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # the arithmetic the estimator runs in: the MI estimators accumulate in fp64 like the reference's
+            # computeMutualInformation*<double>, the others in fp32 (ranks are integers)
+            "dtype": "f64" if measure in (3, 4, 5, 6) else "f32", "data": "synthetic",
             "ranks_seen": ranks_seen, "backend": exchange,
             "config": {"workload": f"{args.measure} correlation field, {xs}x{ys}x{zs} grid x {cs} ensemble members "
                                    "(synthetic box ensemble), one moving reference point per step",

@@ -271,19 +271,31 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
 // the occupancy at 1.5 waves per SIMD).
 // SYM (symmetric field mode): the X side is voxel dependent too -- x_e = members_x[e][v] + noise_ref[e] (prep_px then
 // points at the noise_ref table), X counts by comparison like the Y counts instead of the binary search.
+// Occupancy the register allocator is held to (waves per SIMD): what the instantiations reached before the work split
+// below was added; left to itself the compiler now settles one step lower for K <= 2 and <8, 4>.
+constexpr int direct_min_waves(int K, int TI, bool SYM) {
+    if (SYM) return K <= 8 ? 2 : (K <= 32 ? 3 : 2);
+    return K <= 2 ? 4 : (K == 3 ? 3 : (K == 4 ? 2 : (K <= 32 ? 3 : 1)));
+}
+
 template <int K, int TI, bool SYM = false>
-__global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const* __restrict__ members,
+__global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_direct_kernel(const float* const* __restrict__ members,
                                                             const float* const* __restrict__ members_x,
                                                             const double* __restrict__ prep_px,
                                                             const double* __restrict__ table_psi,
                                                             const double* __restrict__ noise_query,
                                                             float* __restrict__ out, size_t num_voxels, int cs, int k,
-                                                            int estimator, int to_cc, double c_term) {
+                                                            int estimator, int to_cc, double c_term, int share) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* s_px = reinterpret_cast<double*>(smem);  // member order
     double* s_spx = s_px + cs;                       // ascending
     double* s_nq = s_spx + cs;
+    // partial sums of the block's 4 tiles, one slot per (tile, wave): [16][64] x (sum_x, sum_y, NaN flag)
+    __shared__ double s_sum_x[16 * 64];
+    __shared__ double s_sum_y[16 * 64];
+    __shared__ int s_nan[16 * 64];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));  // uniform: i0 below stays in SGPRs
     for (int i = threadIdx.x; i < cs; i += 256) {
         s_px[i] = prep_px[i];                         // SYM: noise_ref[i]
         s_spx[i] = SYM ? 0.0 : prep_px[cs + i];
@@ -298,14 +310,34 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
     const double factor = 1.0 / double(cs);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     const size_t tiles = (num_voxels + 63) / 64;
+    const size_t groups = (tiles + 3) / 4;
+    const int passes = (cs + TI - 1) / TI;
+    // A block takes 4 voxel tiles at a time = 4 * passes work items (tile, TI points).  share: the items are dealt to
+    // the waves round-robin, so the four waves work on the SAME tile at the same time (for passes % 4 == 0; on two
+    // neighbouring tiles otherwise) and the cs / TI re-reads of a tile's member values come from the CU's L1 / the
+    // XCD's L2 -- with a tile per wave (share = 0) a CU's 12 waves cycle through 12 x cs x 256 B, ~6 MB per XCD, and
+    // the re-reads miss the 4 MB L2 (measured: 48 GB fetched per 256^3 x 64 evaluation, 11x the volume).  The waves'
+    // partial sums meet in LDS; the order of the additions depends on cs and TI only, not on the grid.
 #pragma unroll 1
-    for (size_t tile = size_t(blockIdx.x) * 4 + (threadIdx.x >> 6); tile < tiles; tile += size_t(gridDim.x) * 4) {
+    for (size_t group = blockIdx.x; group < groups; group += gridDim.x) {
+#pragma unroll
+      for (int t4 = 0; t4 < 4; t4++) {
+          s_sum_x[(t4 * 4 + wave) * 64 + lane] = 0.0;
+          s_sum_y[(t4 * 4 + wave) * 64 + lane] = 0.0;
+          s_nan[(t4 * 4 + wave) * 64 + lane] = 0;
+      }
+#pragma unroll 1
+      for (int t4 = 0; t4 < 4; t4++) {
+        const size_t tile = group * 4 + size_t(share ? t4 : wave);
+        if (tile >= tiles || (!share && t4 > 0)) continue;
         const size_t v = tile * 64 + lane;
         const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
         bool is_nan = false;
         double sum_x = 0.0, sum_y = 0.0;
+        // share: the 4 * passes items (tile, TI points) of the group are dealt to the waves round-robin
+        const int first = share ? (wave - t4 * passes) & 3 : 0;
 #pragma unroll 1
-        for (int i0 = 0; i0 < cs; i0 += TI) {
+        for (int i0 = first * TI; i0 < cs; i0 += (share ? 4 : 1) * TI) {
             double pxi[TI], pyi[TI], dk[TI], rx[TI], ry[TI];
             double best[TI][K];
 #pragma unroll
@@ -441,13 +473,39 @@ __global__ __launch_bounds__(256) void kraskov_direct_kernel(const float* const*
                 }
             }
         }
+        const int slot = ((share ? t4 : wave) * 4 + wave) * 64 + lane;
+        s_sum_x[slot] = sum_x;
+        s_sum_y[slot] = sum_y;
+        s_nan[slot] = is_nan ? 1 : 0;
+      }
+      __syncthreads();
+      {   // wave w finishes tile w of the group
+        double sum_x = 0.0, sum_y = 0.0;
+        int is_nan = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            sum_x += s_sum_x[(wave * 4 + w) * 64 + lane];
+            sum_y += s_sum_y[(wave * 4 + w) * 64 + lane];
+            is_nan |= s_nan[(wave * 4 + w) * 64 + lane];
+        }
+        const size_t v = (group * 4 + size_t(wave)) * 64 + lane;
         const double mi = -sum_x - sum_y + c_term + table_psi[cs];
         float res = float(mi);
         res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
         if (to_cc) res = mi_to_cc(res);
         if (is_nan) res = __uint_as_float(0x7FC00000u);
         if (v < num_voxels) store_result_nt(out + v, res);
+      }
+      __syncthreads();
     }
+}
+
+// LDS of kraskov_direct_kernel's partial sums: 16 (tile, wave) slots x 64 lanes x (2 doubles + 1 int)
+constexpr size_t kDirectSumBytes = 16 * 64 * (2 * sizeof(double) + sizeof(int));
+
+static int direct_share_tiles() {
+    const char* e = getenv("CRF_KRASKOV_SHARE");  // tuning: 0 = a voxel tile per wave (the round-1 work split)
+    return !(e && e[0] == '0');
 }
 
 void launch_kraskov_prep(const RefSource& ref, const float* const* d_members, int cs, const double* noise_ref,
@@ -463,7 +521,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
                                     hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
     const int kk = a.k < cs - 1 ? a.k : cs - 1;
     const size_t lds = size_t(3 * cs) * sizeof(double);
-    if (kk > 128 || lds > 60 * 1024) return hipErrorNotSupported;
+    if (kk > 128 || lds + kDirectSumBytes > 60 * 1024) return hipErrorNotSupported;
     const double* psi = d_tables;
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
@@ -472,11 +530,16 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     if (!ref.run()) return hipGetLastError();
     const size_t tiles = (num_voxels + 63) / 64;
     const size_t groups = (tiles + 3) / 4;
-    const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
+    // one block per group of four voxel tiles up to 65536 blocks (r01 capped the grid at 4096: with ~768 blocks resident
+    // that is 5.3 rounds of equally long blocks, the last round a third full)
+    const char* cap_env = getenv("CRF_KRASKOV_GRID");  // tuning
+    const size_t cap = cap_env && atoi(cap_env) > 0 ? size_t(atoi(cap_env)) : 65536;
+    const unsigned blocks = unsigned(groups < cap ? groups : cap);
+    const int share = direct_share_tiles();
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
 #define CRF_LAUNCH_DIRECT(K, TI)                                                                                    \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, prep, psi, \
-                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
+                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
     // K = k exactly for the small k (the sorted insertion costs 2K - 1 min/max per candidate: K = 4 for k = 3 is 7
     // instead of 5; measured at 256^3 x 64, k = 3: <3, 8> 36.2 ms vs <4, 8> 48.6 ms)
     if (kk == 1) {
@@ -511,16 +574,17 @@ hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const fl
     if (cs == 1) return launch_fill(d_out, num_voxels, 1.0f, s);
     const int kk = k < cs - 1 ? k : cs - 1;
     const size_t lds = size_t(3 * cs) * sizeof(double);
-    if (kk > 64 || lds > 60 * 1024) return hipErrorNotSupported;
+    if (kk > 64 || lds + kDirectSumBytes > 60 * 1024) return hipErrorNotSupported;
     const double* psi = d_tables;
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     const size_t tiles = (num_voxels + 63) / 64;
     const size_t groups = (tiles + 3) / 4;
-    const unsigned blocks = unsigned(groups < 4096 ? groups : 4096);
+    const unsigned blocks = unsigned(groups < 65536 ? groups : 65536);
+    const int share = direct_share_tiles();
 #define CRF_LAUNCH_SYM(K, TI)                                                                                        \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, true>), dim3(blocks), dim3(256), lds, s, d_members_y, d_members_x, \
-                       noise_ref, psi, noise_query, d_out, num_voxels, cs, k, 1, int(to_cc), c_term)
+                       noise_ref, psi, noise_query, d_out, num_voxels, cs, k, 1, int(to_cc), c_term, share)
     if (kk == 1) {
         CRF_LAUNCH_SYM(1, 8);
     } else if (kk == 2) {
@@ -559,14 +623,14 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
     // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 56 members the
-    // LDS-column kernel with 8 points per sweep wins (its column is small enough for three waves per SIMD): k = 3 at 32 /
-    // 48 members 9.1 / 18.7 ms vs 10.6 / 21.0 ms tile-free.  At 57..64 members the column allows two waves; k = 3 is a
-    // tie (36.7 vs 35.4 ms) and stays on the tile kernel, whose HBM traffic equals the algorithmic bytes (the tile-free
-    // kernel re-reads the members 16 times through L2 / the Infinity Cache: 47.9 GB at the fabric counters for 4.36 GB);
-    // k = 1 and k = 2 take the tile-free kernel (27.1 vs 31.0 ms, 27.9 vs 33.4 ms).  From 65 members on the tile-free
-    // kernel wins for every k (80 members, k = 3: 52.7 vs 67.7 ms).
+    // LDS-column kernel with 8 points per sweep wins for k = 3 / 4 (its column is small enough for three waves per SIMD:
+    // k = 3 at 32 / 48 members 9.1 / 18.7 ms vs 10.2 / 19.6 ms tile-free); for k = 1 / 2 the tile-free kernel (four
+    // waves per SIMD) is ahead from ~44 members on (48 members: 13.9 / 15.2 ms vs 14.8 / 17.2 ms).  From 57 members on
+    // the column allows two waves only and the tile-free kernel wins for every k (64 members, k = 1..4: 23.1 / 25.7 /
+    // 33.8 / 47.4 ms vs 31.0 / 33.4 / 36.7 / 49.4 ms; 80 members, k = 3: 49.5 vs 67.7 ms) -- since its four waves share
+    // a voxel tile its re-reads stay in L1 / L2 (see the kernel).
     const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
-    const bool prefer_direct = cs > 64 || (cs > 56 && (kk == 1 || kk == 2));
+    const bool prefer_direct = cs > 56 || (cs > 44 && kk <= 2);
     if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
         (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
