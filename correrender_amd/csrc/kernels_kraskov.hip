@@ -84,6 +84,26 @@ __device__ __forceinline__ int count_less(const double* tab, int n, int top, dou
     return pos;
 }
 
+// The same search for NCH bounds at once: the steps are the outer loop, so a step issues NCH independent LDS reads before
+// it waits (one search after the other is a chain of log2(n) dependent LDS round trips each -- and the && above
+// compiles to exec-masked branches; at 8 points x 2 bounds per sweep that latency was as long as the k-select itself).
+template <int NCH>
+__device__ __forceinline__ void count_less_batch(const double* tab, int n, int top, const double (&v)[NCH],
+                                                 int (&pos)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) pos[c] = 0;
+#pragma unroll 1
+    for (int step = top; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int idx = pos[c] + step;
+            const bool ok = idx <= n;
+            const double val = tab[(ok ? idx : n) - 1];
+            pos[c] = (ok & (val < v[c])) ? idx : pos[c];
+        }
+    }
+}
+
 // K > 0: the K = k nearest OTHER points are kept in registers (sorted insertion: min/max only).  K == 0: any k,
 // selection by repeated minimum passes.  TI points are processed concurrently per lane.
 template <int K, int TI>
@@ -223,10 +243,20 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
         //      reference coordinates (like the reference); y: compares against every point.
         double loy[TI], hiy[TI];
         int cx[TI], cy[TI];
+        {
+            double bound[TI];
+            int less[TI];
+#pragma unroll
+            for (int t = 0; t < TI; t++) bound[t] = pxi[t] + rx[t];
+            count_less_batch<TI>(s_spx, cs, top, bound, cx);
+#pragma unroll
+            for (int t = 0; t < TI; t++) bound[t] = pxi[t] - rx[t];
+            count_less_batch<TI>(s_spx, cs, top, bound, less);
+#pragma unroll
+            for (int t = 0; t < TI; t++) cx[t] -= less[t];
+        }
 #pragma unroll
         for (int t = 0; t < TI; t++) {
-            const double lox = pxi[t] - rx[t], hix = pxi[t] + rx[t];
-            cx[t] = count_less(s_spx, cs, top, hix) - count_less(s_spx, cs, top, lox);
             loy[t] = pyi[t] - ry[t];
             hiy[t] = pyi[t] + ry[t];
             cy[t] = 0;
@@ -431,10 +461,16 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
             for (int t = 0; t < TI; t++) {
                 lox[t] = pxi[t] - rx[t];
                 hix[t] = pxi[t] + rx[t];
-                cx[t] = SYM ? 0 : count_less(s_spx, cs, top, hix[t]) - count_less(s_spx, cs, top, lox[t]);
                 loy[t] = pyi[t] - ry[t];
                 hiy[t] = pyi[t] + ry[t];
-                cy[t] = 0;
+                cx[t] = cy[t] = 0;
+            }
+            if constexpr (!SYM) {
+                int less[TI];
+                count_less_batch<TI>(s_spx, cs, top, hix, cx);
+                count_less_batch<TI>(s_spx, cs, top, lox, less);
+#pragma unroll
+                for (int t = 0; t < TI; t++) cx[t] -= less[t];
             }
 #pragma unroll 1
             for (int j0 = 0; j0 < cs; j0 += JB) {
@@ -497,6 +533,250 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
         if (v < num_voxels) store_result_nt(out + v, res);
       }
       __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Up to 64 members, k <= 4: the tile-free kernel with the y counts taken by binary search (r02).  A block works on ONE
+// 64-voxel tile at a time: one of its four waves (rotating with the tile, so the extra work spreads over the SIMDs)
+// loads the voxel's cs query values, sorts py_e = y_e + noise_e with a register min/max network and parks the sorted
+// column in LDS [rank][lane]; after the barrier the four waves split the tile's points (8 per sweep) and take
+// #{ j : lo <= py_j < hi } as lower_bound(hi) - lower_bound(lo) in the lane's column -- 2 x 7 probes instead of cs
+// compare pairs (3.4 of the ~13 vector instructions per point pair).  Same counts as the compare sweep: the column
+// holds the same py values, pads are +inf (below no finite bound; a NaN voxel is flagged, its result discarded).
+// ---------------------------------------------------------------------------------------------------------------
+// lower_bound in the lane's sorted column (base + lane, stride 64) for NCH bounds at once, steps outermost as above
+template <int NS, int NCH>
+__device__ __forceinline__ void count_less_column_batch(const double* col, const double (&v)[NCH], int (&pos)[NCH]) {
+    constexpr bool kPow2 = (NS & (NS - 1)) == 0;
+    // NS a power of two: the last entry is tested on its own, the search runs over the first NS - 1 (probe index < NS - 1)
+    constexpr int kTop = kPow2 ? NS / 2 : (NS >= 32 ? 32 : (NS >= 16 ? 16 : 8));
+#pragma unroll
+    for (int c = 0; c < NCH; c++) pos[c] = 0;
+#pragma unroll
+    for (int step = kTop; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int idx = pos[c] + step;
+            if constexpr (kPow2) {
+                pos[c] = col[(idx - 1) * 64] < v[c] ? idx : pos[c];
+            } else {
+                const bool ok = idx <= NS;
+                const double val = col[((ok ? idx : NS) - 1) * 64];
+                pos[c] = (ok & (val < v[c])) ? idx : pos[c];
+            }
+        }
+    }
+    if constexpr (kPow2) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) pos[c] = col[(NS - 1) * 64] < v[c] ? NS : pos[c];
+    }
+}
+
+// waves per SIMD the allocator is asked for; the sort holds NS doubles in registers
+constexpr int sorted_min_waves(int K, int NS) {
+    const int main_phase = K <= 2 ? 4 : (K == 3 ? 3 : 2);
+    const int sort_phase = NS <= 48 ? 3 : 2;
+    return main_phase < sort_phase ? main_phase : sort_phase;
+}
+
+template <int K, int NS, int NW>
+__global__ __launch_bounds__(64 * NW, sorted_min_waves(K, NS)) void kraskov_sorted_kernel(
+    const float* const* __restrict__ members, const double* __restrict__ prep_px, const double* __restrict__ table_psi,
+    const double* __restrict__ noise_query, float* __restrict__ out, size_t num_voxels, int cs, int k, int estimator,
+    int to_cc, double c_term) {
+    constexpr int TI = 8;
+    constexpr int JB = 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* s_px = reinterpret_cast<double*>(smem);  // member order
+    double* s_spx = s_px + cs;                       // ascending
+    double* s_nq = s_spx + cs;
+    __shared__ double s_col[NS * 64];  // the tile's py values, ascending per lane: [rank][lane]
+    __shared__ double s_sum_x[NW * 64];
+    __shared__ double s_sum_y[NW * 64];
+    __shared__ int s_nan[NW * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    for (int i = threadIdx.x; i < cs; i += 64 * NW) {
+        s_px[i] = prep_px[i];
+        s_spx[i] = prep_px[cs + i];
+        s_nq[i] = noise_query[i];
+    }
+    __syncthreads();
+    const uint32_t bytes = uint32_t(num_voxels) * 4u;
+    const int kk = k < cs - 1 ? k : cs - 1;
+    int top = 1;
+    while (top * 2 <= cs) top *= 2;
+    const double factor = 1.0 / double(cs);
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const size_t tiles = (num_voxels + 63) / 64;
+    const double* col = s_col + lane;
+#pragma unroll 1
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const size_t v = tile * 64 + lane;
+        const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+        {   // every wave fetches a quarter of the members (one batch of loads) and parks py in the column, member order
+            static_assert(NS % NW == 0, "members per wave");
+            constexpr int Q = NS / NW;
+            float yq[Q];
+            bool is_nan = false;
+#pragma unroll
+            for (int u = 0; u < Q; u++) {
+                const int j = wave * Q + u;
+                yq[u] = load_member_cached(members[j < cs ? j : cs - 1], bytes, off);
+            }
+#pragma unroll
+            for (int u = 0; u < Q; u++) {
+                const int j = wave * Q + u;
+                is_nan |= (j < cs) && (yq[u] != yq[u]);
+                s_col[j * 64 + lane] = j < cs ? double(yq[u]) + s_nq[j < cs ? j : cs - 1] : inf;
+            }
+            s_nan[wave * 64 + lane] = is_nan ? 1 : 0;
+        }
+        __syncthreads();
+        if (wave == int(tile % NW)) {  // one wave sorts the column in registers
+            composite_t a[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) a[j] = s_col[j * 64 + lane];
+            SortNet<NS>::sort(a);
+#pragma unroll
+            for (int j = 0; j < NS; j++) s_col[j * 64 + lane] = a[j];
+        }
+        __syncthreads();
+        double sum_x = 0.0, sum_y = 0.0;
+#pragma unroll 1
+        for (int i0 = wave * TI; i0 < cs; i0 += NW * TI) {
+            double pxi[TI], pyi[TI], dk[TI], rx[TI], ry[TI];
+            double best[TI][K];
+            float yi[TI];
+#pragma unroll
+            for (int t = 0; t < TI; t++) yi[t] = load_member_cached(members[(i0 + t < cs) ? i0 + t : cs - 1], bytes, off);
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
+                pxi[t] = s_px[ii];
+                pyi[t] = double(yi[t]) + s_nq[ii];
+#pragma unroll
+                for (int q = 0; q < K; q++) best[t][q] = inf;
+            }
+            // ---- sweep A: as kraskov_direct_kernel
+#pragma unroll 1
+            for (int j0 = 0; j0 < cs; j0 += JB) {
+                float yb[JB];
+#pragma unroll
+                for (int u = 0; u < JB; u++)
+                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+#pragma unroll
+                for (int u = 0; u < JB; u++) {
+                    const int j = j0 + u;
+                    const int jc = j < cs ? j : cs - 1;
+                    const double pxj = j < cs ? s_px[jc] : inf;
+                    const double pyj = j < cs ? double(yb[u]) + s_nq[jc] : inf;
+#pragma unroll
+                    for (int t = 0; t < TI; t++) {
+                        double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
+                        const uint64_t bits = uint64_t(__double_as_longlong(d));
+                        const uint32_t hi = (j == i0 + t) ? 0x7FEFFFFFu : uint32_t(bits >> 32);
+                        d = __longlong_as_double((long long)((uint64_t(hi) << 32) | uint32_t(bits)));
+#pragma unroll
+                        for (int q = 0; q < K; q++) {
+                            const double lo = min_f64(best[t][q], d);
+                            if (q + 1 < K) d = max_f64(best[t][q], d);
+                            best[t][q] = lo;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                double sel = best[t][0];
+#pragma unroll
+                for (int q = 1; q < K; q++) sel = (q == kk - 1) ? best[t][q] : sel;
+                dk[t] = sel;
+            }
+            if (estimator == 1) {
+#pragma unroll
+                for (int t = 0; t < TI; t++) rx[t] = ry[t] = dk[t] - kCountSlack;  // includeCenter, :196-197
+            } else {
+                double ex[TI], ey[TI];
+#pragma unroll
+                for (int t = 0; t < TI; t++) ex[t] = ey[t] = 0.0;
+#pragma unroll 2
+                for (int j = 0; j < cs; j++) {
+                    const double pxj = s_px[j];
+                    const double pyj = double(load_member_cached(members[j], bytes, off)) + s_nq[j];
+#pragma unroll
+                    for (int t = 0; t < TI; t++) {
+                        const double ax = fabs(pxi[t] - pxj), ay = fabs(pyi[t] - pyj);
+                        const bool in = fmax(ax, ay) <= dk[t];
+                        ex[t] = in ? fmax(ex[t], ax) : ex[t];
+                        ey[t] = in ? fmax(ey[t], ay) : ey[t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TI; t++) {
+                    rx[t] = ex[t] + kCountSlack;
+                    ry[t] = ey[t] + kCountSlack;
+                }
+            }
+            // ---- marginal counts (:201-233): both by binary search (all of them first: 32 independent probe chains)
+            int cx[TI], cy[TI];
+            {
+                double bound[TI];
+                int less[TI];
+#pragma unroll
+                for (int t = 0; t < TI; t++) bound[t] = pxi[t] + rx[t];
+                count_less_batch<TI>(s_spx, cs, top, bound, cx);
+#pragma unroll
+                for (int t = 0; t < TI; t++) bound[t] = pxi[t] - rx[t];
+                count_less_batch<TI>(s_spx, cs, top, bound, less);
+#pragma unroll
+                for (int t = 0; t < TI; t++) cx[t] -= less[t];
+#pragma unroll
+                for (int t = 0; t < TI; t++) bound[t] = pyi[t] + ry[t];
+                count_less_column_batch<NS, TI>(col, bound, cy);
+#pragma unroll
+                for (int t = 0; t < TI; t++) bound[t] = pyi[t] - ry[t];
+                count_less_column_batch<NS, TI>(col, bound, less);
+#pragma unroll
+                for (int t = 0; t < TI; t++) {
+                    cy[t] -= less[t];
+                    cy[t] = cy[t] > 0 ? cy[t] : 0;  // an empty [lo, hi) with lo > hi
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+                if (i0 + t < cs) {
+                    int nx = cx[t] > 1 ? cx[t] : 1;
+                    int ny = cy[t] > 1 ? cy[t] : 1;
+                    if (estimator != 1) {
+                        nx -= 1;  // psi(n - 1), psi(0) = NaN (pole)
+                        ny -= 1;
+                    }
+                    sum_x += factor * table_psi[nx];
+                    sum_y += factor * table_psi[ny];
+                }
+            }
+        }
+        s_sum_x[wave * 64 + lane] = sum_x;
+        s_sum_y[wave * 64 + lane] = sum_y;
+        __syncthreads();
+        if (wave == int((tile + 1) % NW)) {
+            double tx = 0.0, ty = 0.0;
+            int any_nan = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                tx += s_sum_x[w * 64 + lane];
+                ty += s_sum_y[w * 64 + lane];
+                any_nan |= s_nan[w * 64 + lane];
+            }
+            const double mi = -tx - ty + c_term + table_psi[cs];
+            float res = float(mi);
+            res = (res < 0.0f) ? 0.0f : res;  // std::max(float(mi), 0.0f), :443
+            if (to_cc) res = mi_to_cc(res);
+            if (any_nan) res = __uint_as_float(0x7FC00000u);
+            if (v < num_voxels) store_result_nt(out + v, res);
+        }
     }
 }
 
@@ -567,6 +847,46 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     return hipGetLastError();
 }
 
+// sorted-column kernel: cs <= 64, k <= 4
+hipError_t launch_mi_kraskov_sorted(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
+                                    const KraskovArgs& a, const double* d_tables, float* d_prep, float* d_out,
+                                    hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+    const int kk = a.k < cs - 1 ? a.k : cs - 1;
+    if (kk > 4 || kk < 1 || cs > 64) return hipErrorNotSupported;
+    const size_t lds = size_t(3 * cs) * sizeof(double);
+    const double* psi = d_tables;
+    const double* noise_ref = d_tables + 2 * (cs + 1);
+    const double* noise_query = noise_ref + cs;
+    double* prep = reinterpret_cast<double*>(d_prep);
+    if (ref.prepare()) launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
+    if (!ref.run()) return hipGetLastError();
+    const size_t tiles = (num_voxels + 63) / 64;
+    const unsigned blocks = unsigned(tiles < 65536 ? tiles : 65536);
+    if (ev_begin) (void)hipEventRecord(ev_begin, s);
+#define CRF_LAUNCH_SORTED(K, NS)                                                                                     \
+    hipLaunchKernelGGL((kraskov_sorted_kernel<K, NS, 2>), dim3(blocks), dim3(128), lds, s, d_members, prep, psi,      \
+                       noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
+#define CRF_LAUNCH_SORTED_K(NS)                   \
+    switch (kk) {                                 \
+        case 1: CRF_LAUNCH_SORTED(1, NS); break;  \
+        case 2: CRF_LAUNCH_SORTED(2, NS); break;  \
+        case 3: CRF_LAUNCH_SORTED(3, NS); break;  \
+        default: CRF_LAUNCH_SORTED(4, NS); break; \
+    }
+    if (cs <= 32) {
+        CRF_LAUNCH_SORTED_K(32)
+    } else if (cs <= 48) {
+        CRF_LAUNCH_SORTED_K(48)
+    } else {
+        CRF_LAUNCH_SORTED_K(64)
+    }
+#undef CRF_LAUNCH_SORTED_K
+#undef CRF_LAUNCH_SORTED
+    if (ev_end) (void)hipEventRecord(ev_end, s);
+    if (info) info->kernel_name = "kraskov_sorted_kernel";
+    return hipGetLastError();
+}
+
 // symmetric field mode: X = d_members_x (reference field), Y = d_members_y (query field); KSG-1
 hipError_t launch_mi_kraskov_symmetric(const float* const* d_members_x, const float* const* d_members_y, int cs,
                                        size_t num_voxels, int k, double c_term, bool to_cc, const double* d_tables,
@@ -623,14 +943,20 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
     // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 56 members the
-    // LDS-column kernel with 8 points per sweep wins for k = 3 / 4 (its column is small enough for three waves per SIMD:
-    // k = 3 at 32 / 48 members 9.1 / 18.7 ms vs 10.2 / 19.6 ms tile-free); for k = 1 / 2 the tile-free kernel (four
-    // waves per SIMD) is ahead from ~44 members on (48 members: 13.9 / 15.2 ms vs 14.8 / 17.2 ms).  From 57 members on
-    // the column allows two waves only and the tile-free kernel wins for every k (64 members, k = 1..4: 23.1 / 25.7 /
-    // 33.8 / 47.4 ms vs 31.0 / 33.4 / 36.7 / 49.4 ms; 80 members, k = 3: 49.5 vs 67.7 ms) -- since its four waves share
-    // a voxel tile its re-reads stay in L1 / L2 (see the kernel).
+    // LDS-column kernel with 8 points per sweep wins (its column is small enough for three waves per SIMD: k = 3 at 32 /
+    // 48 / 56 members 8.1 / 16.4 / 23.9 ms vs 8.3 / 16.7 ms tile-free) except for k = 2 from ~44 members on (48 members:
+    // 13.5 vs 14.6 ms).  From 57 members on the column allows two waves only and the tile-free kernel wins (64 members,
+    // k = 1..4: 20.0 / 23.1 / 28.8 / 39.8 ms; 80 members, k = 3: 43.7 ms) -- its four waves share a voxel tile, so its
+    // re-reads stay in L1 / L2 (see the kernel).  k = 4 at 57..64 members goes to the sorted-column kernel (35.0 ms).
+    const char* sorted = getenv("CRF_KRASKOV_SORTED");  // tuning: 1 = wherever it exists, 0 = never
+    if (kk <= 4 && cs <= 64 && !(sorted && *sorted == '0') && !(force_direct && *force_direct == '1') &&
+        ((sorted && *sorted == '1') || (cs > 56 && kk == 4))) {
+        hipError_t e = launch_mi_kraskov_sorted(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
+                                                ev_end, info);
+        if (e != hipErrorNotSupported) return e;
+    }
     const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
-    const bool prefer_direct = cs > 56 || (cs > 44 && kk <= 2);
+    const bool prefer_direct = cs > 56 || (cs > 44 && kk == 2);
     if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
         (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,

@@ -136,6 +136,28 @@ def test_binned_positive_overflow_of_the_bin_index(engine, oracle, cs):
         assert_close(got, want, f"binned bin-index overflow cs={cs} ref={ref}")
 
 
+@pytest.mark.parametrize("variant", ["CRF_KRASKOV_SORTED", "CRF_KRASKOV_DIRECT", "CRF_KRASKOV_TILE"])
+@pytest.mark.parametrize("cs", [9, 20, 32, 33, 47, 48, 57, 63, 64])
+def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, cs):
+    """The three Kraskov kernels (sorted-column, tile-free, LDS-column) forced one at a time -- the dispatch picks one per
+    (cs, k), so without this a kernel is only exercised where it is the default; the launchers read the variable at
+    every call.  Includes a box ensemble (exact ties, resolved by the noise), a NaN voxel and both estimators."""
+    monkeypatch.setenv(variant, "1")
+    for k in (1, 2, 3, 4):
+        for estimator in (1, 2):
+            ens = synth.normal_ensemble(16, 6, 5, cs, seed=70 * cs + k)
+            ens[3 % cs, 1, 2, 3] = np.nan
+            _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
+                   f"{variant} KSG-{estimator} cs={cs} k={k}", ref_xyz=(2, 1, 0), k=k,
+                   kraskov_estimator_index=estimator, min_identical=0.99)
+    box = synth.box_ensemble(16, 6, 5, cs, seed=cs)
+    _check(engine, oracle, box, Measure.KMI_CORRELATION_COEFFICIENT, oracle_lib.KMI_CC,
+           f"{variant} box ensemble cs={cs}", ref_xyz=(5, 2, 1), k=3, min_identical=0.98)
+    expected = {"CRF_KRASKOV_SORTED": "kraskov_sorted_kernel", "CRF_KRASKOV_DIRECT": "kraskov_direct_kernel",
+                "CRF_KRASKOV_TILE": "mi_kraskov_kernel"}[variant]
+    assert engine.last_kernel_name() == expected
+
+
 @pytest.mark.parametrize("cs,k", [(16, 2), (64, 3), (100, 5), (64, 12), (100, 40), (160, 70)])
 def test_kraskov_ksg2(engine, oracle, cs, k):
     ens = synth.normal_ensemble(16, 8, 6, cs, seed=400 + cs)
