@@ -215,9 +215,14 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     }
     __builtin_amdgcn_sched_barrier(0);
     // ranks back in member order (same lane wrote them: program order suffices, no barrier)
+    // (all reads first, then the conversions: this file is compiled without the machine scheduler, and read / convert
+    // per element was one LDS round trip per member -- 64 dependent waits, tools/isa_lds_chains.py)
     float r[N];
+    uint32_t raw[N];
 #pragma unroll
-    for (int e = 0; e < N; e++) r[e] = (EXACT || e < SURE || e < cs) ? 0.5f * float(rank2[e * 64 + lane]) : 0.0f;
+    for (int e = 0; e < N; e++) raw[e] = rank2[e * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < N; e++) r[e] = (EXACT || e < SURE || e < cs) ? 0.5f * float(raw[e]) : 0.0f;
     float res = pearson_tail<N, EXACT, SURE>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) store_result_nt(out + v, res);
@@ -348,6 +353,36 @@ __device__ __forceinline__ uint32_t lower_bound_col(const uint32_t* col, uint32_
     return pos + ((k < key) ? 1u : 0u);
 }
 
+// The same search for G keys at once, the steps as the outer loop: a step issues G independent LDS reads before it
+// waits.  One search after the other is a chain of log2(CH) + 1 dependent LDS round trips each; the compiler paired
+// them at best (ISA of r01: ds_read, ds_read, s_waitcnt lgkmcnt(1), lgkmcnt(0), ...), 64 x 7 / 2 round trips per voxel.
+template <int CH, int G>
+__device__ __forceinline__ void lower_bound_col_batch(const uint32_t* col, const uint32_t (&key)[G], uint32_t& tie_min,
+                                                      uint32_t (&less)[G]) {
+    uint32_t pos[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) pos[g] = 0;
+#pragma unroll
+    for (int s = CH / 2; s >= 1; s >>= 1) {
+        uint32_t probe[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) probe[g] = col[(pos[g] + uint32_t(s) - 1u) * 64u];
+        __builtin_amdgcn_sched_barrier(0);  // (without the fences the instruction selector re-pairs the chains)
+#pragma unroll
+        for (int g = 0; g < G; g++) pos[g] += (probe[g] < key[g]) ? uint32_t(s) : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t k[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) k[g] = col[pos[g] * 64u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        tie_min = min(tie_min, k[g] ^ key[g]);
+        less[g] = pos[g] + ((k[g] < key[g]) ? 1u : 0u);
+    }
+}
+
 // loads slots base..base+CH-1 of the lane's voxel as composites (low word = slot - base), pads beyond cs
 // SURE: the first SURE slots of the chunk are members whatever cs is (caller's contract): no guard on them
 template <int CH, bool EXACT, bool PERMUTED, int SURE = 0>
@@ -420,17 +455,40 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
+        constexpr int G = 4;  // searches in flight (8: scratch in the 64 + 64 and 32 + 32 kernels)
+        // The last 8 slots may be pads (wave-uniform, p >= nB).  When they are all members (cs = CH + CHB) the last batch
+        // runs like the others; otherwise element by element behind wave-uniform branches (8 x 7 serial LDS round
+        // trips; the select-masked batch form of it costs 270 B of scratch here).
 #pragma unroll
-        for (int p = 0; p < CHB; p++) {
-            infoB[p] = 0u;
-            if (EXACT || p < SURE_B || p < nB) {  // (a branch-free form of this loop was measured 20-45 % slower: scratch)
-                const uint32_t key = composite_key(b[p]);
-                if (p > 0) tie_min = min(tie_min, key ^ prev);
-                if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CHB - 1 : (p >= SURE_B && p == nB - 1)) is_nan |= key > 0xFF800000u;
-                prev = key;
-                const uint32_t less = lower_bound_col<CH>(&lds[lane], key, tie_min);  // #{A < b_p}, 0..CH
-                infoB[p] = less | ((composite_low(b[p]) & 0xFFu) << 8);
+        for (int p0 = 0; p0 < CHB; p0 += G) {
+            const bool guarded = !EXACT && p0 >= SURE_B;  // compile time per batch
+            if (!guarded || p0 + G <= nB) {
+                uint32_t key[G], less[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int p = p0 + g;
+                    key[g] = composite_key(b[p]);
+                    if (p > 0) tie_min = min(tie_min, key[g] ^ prev);
+                    if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
+                    if (p == CHB - 1) is_nan |= key[g] > 0xFF800000u;  // (guarded batch taken: nB == CHB)
+                    prev = key[g];
+                }
+                lower_bound_col_batch<CH, G>(&lds[lane], key, tie_min, less);  // #{A < b_p}, 0..CH
+#pragma unroll
+                for (int g = 0; g < G; g++) infoB[p0 + g] = less[g] | ((composite_low(b[p0 + g]) & 0xFFu) << 8);
+            } else {
+#pragma unroll
+                for (int p = p0; p < p0 + G; p++) {
+                    infoB[p] = 0u;
+                    if (p < nB) {
+                        const uint32_t key = composite_key(b[p]);
+                        if (p > 0) tie_min = min(tie_min, key ^ prev);
+                        if (p == 0) is_nan |= key < 0x007FFFFFu;
+                        if (p == nB - 1) is_nan |= key > 0xFF800000u;
+                        prev = key;
+                        infoB[p] = lower_bound_col<CH>(&lds[lane], key, tie_min) | ((composite_low(b[p]) & 0xFFu) << 8);
+                    }
+                }
             }
         }
     }
@@ -438,6 +496,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     // LDS is re-used from here on (this lane's binary searches are complete; LDS operations of a wave stay in order)
     uint8_t* pos_of = reinterpret_cast<uint8_t*>(lds);  // [slot 0..2CH-1][lane]: 0-based position in the union
     uint8_t* hist = pos_of + (CH + CHB) * 64;               // [0..CH][lane]: #{b : #{A < b} == t}
+    // hist[t] = #{b : #{A < b} <= t} for the t that occur, 0 elsewhere: B is sorted, so `less` is non-decreasing in p
+    // and the LAST p of a run of equal `less` leaves p + 1 = the cumulative count (LDS operations of a wave stay in
+    // order).  Stores only: the r01 form incremented hist[less] (read, wait, add, write), 64 dependent LDS round trips.
 #pragma unroll
     for (int t = 0; t <= CH; t++) hist[t * 64 + lane] = 0;
 #pragma unroll
@@ -445,21 +506,34 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         if (EXACT || p < SURE_B || p < nB) {
             const uint32_t less = infoB[p] & 0xFFu;
             const uint32_t slot = infoB[p] >> 8;
-            const uint32_t h = hist[less * 64 + lane];
-            hist[less * 64 + lane] = uint8_t(h + 1u);
+            hist[less * 64 + lane] = uint8_t(p + 1);
             pos_of[(CH + slot) * 64 + lane] = uint8_t(uint32_t(p) + less);
         }
     }
-    uint32_t below = 0;  // #{B < a_q} = #{b : #{A < b} <= q} (no ties)
+    uint32_t below = 0;  // #{B < a_q} = #{b : #{A < b} <= q} (no ties): running maximum of the cumulative counts
 #pragma unroll
-    for (int q = 0; q < CH; q++) {
-        below += uint32_t(hist[q * 64 + lane]);
-        pos_of[uint32_t(slotA[q * 64 + lane]) * 64 + lane] = uint8_t(uint32_t(q) + below);
+    for (int q0 = 0; q0 < CH; q0 += 4) {  // 8 independent reads per step, then the dependent stores
+        uint32_t cum[4], slot[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            cum[g] = uint32_t(hist[(q0 + g) * 64 + lane]);
+            slot[g] = uint32_t(slotA[(q0 + g) * 64 + lane]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            below = max(below, cum[g]);
+            pos_of[slot[g] * 64 + lane] = uint8_t(uint32_t(q0 + g) + below);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     float r[CH + CHB];
+    {
+        uint32_t raw[CH + CHB];  // all reads first (see spearman_kernel)
 #pragma unroll
-    for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < CH + SURE_B || e < cs) ? float(uint32_t(pos_of[e * 64 + lane]) + 1u) : 0.0f;
+        for (int e = 0; e < CH + CHB; e++) raw[e] = pos_of[e * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < CH + SURE_B || e < cs) ? float(raw[e] + 1u) : 0.0f;
+    }
     float res = pearson_tail<CH + CHB, EXACT, CH + SURE_B>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
@@ -554,17 +628,27 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
+        constexpr int G = 8;  // see spearman_split_kernel
 #pragma unroll
-        for (int p = 0; p < CHB; p++) {
-            if (EXACT || p < SURE_B || p < nB) {
-                const uint32_t key = composite_key(b[p]);
-                if (p > 0) tie_min = min(tie_min, key ^ prev);
-                if (p == 0) is_nan |= key < 0x007FFFFFu;
-                if (EXACT ? p == CHB - 1 : (p >= SURE_B && p == nB - 1)) is_nan |= key > 0xFF800000u;
-                prev = key;
-                // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
-                discordant += CH - int32_t(lower_bound_col<CH>(&keysA[lane], key, tie_min));
+        for (int p0 = 0; p0 < CHB; p0 += G) {
+            const bool guarded = !EXACT && p0 >= SURE_B;
+            uint32_t key[G], less[G];
+            uint32_t batch_tie = 0xFFFFFFFFu;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int p = p0 + g;
+                const bool real = !guarded || p < nB;
+                key[g] = composite_key(b[p]);
+                if (p > 0) tie_min = min(tie_min, real ? key[g] ^ prev : 0xFFFFFFFFu);
+                if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
+                if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
+                prev = key[g];
             }
+            lower_bound_col_batch<CH, G>(&keysA[lane], key, guarded ? batch_tie : tie_min, less);
+            if (guarded) tie_min = min(tie_min, batch_tie);
+            // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
+#pragma unroll
+            for (int g = 0; g < G; g++) discordant += (!guarded || p0 + g < nB) ? CH - int32_t(less[g]) : 0;
         }
         discordant += chunk_inversions<CHB, SURE_B>(b, nB, EXACT);
     }
