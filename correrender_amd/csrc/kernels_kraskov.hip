@@ -37,6 +37,11 @@ namespace crf {
 // prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e (MutualInformation.cpp:417-420), member order;
 //                   [cs, 2cs) the same values sorted ascending (the reference sorts them for its 1-D range counts,
 //                   MutualInformation.cpp:187; voxel independent, so sorted once per evaluation)
+// the distance table fits the 64 KB preparation buffer behind the two coordinate vectors up to 80 members
+constexpr int kDxtMaxMembers = 80;
+__host__ __device__ inline int dxt_offset(int cs) { return (2 * cs + 7) / 8 * 8; }  // in doubles
+static_assert(size_t(((2 * kDxtMaxMembers + 7) / 8 * 8) + 80 * 80) * sizeof(double) <= kPrepBytes - 16, "prep buffer");
+
 __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                            int cs, const double* __restrict__ noise_ref,
                                                            double* __restrict__ prep) {
@@ -49,6 +54,20 @@ __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const 
         for (int j = 0; j < cs; j++) rank += (px[j] < v || (px[j] == v && j < e)) ? 1 : 0;
         prep[e] = v;
         prep[cs + rank] = v;
+    }
+    // x-distance table for the tile-free kernel (cs <= kDxtMaxMembers): T[j][i] = |px_i - px_j| for candidate j and
+    // point i, laid out [round_up(cs, 16)][round_up(cs, 8)] behind the two vectors (64-byte aligned).  The diagonal holds
+    // the largest finite double (a point is not its own neighbour) and the rows of candidates past the end +inf, so the
+    // kernel needs neither a self test nor an end test per pair; it reads a row segment of 8 with one scalar load.
+    if (cs <= kDxtMaxMembers) {
+        double* table = prep + dxt_offset(cs);
+        const int rows = (cs + 15) / 16 * 16, cols = (cs + 7) / 8 * 8;
+        for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) {
+            const int j = idx / cols, i = idx - j * cols;
+            double d = __longlong_as_double(0x7FF0000000000000ll);
+            if (j < cs && i < cs) d = (i == j) ? __longlong_as_double(0x7FEFFFFFFFFFFFFFll) : fabs(px[i] - px[j]);
+            table[idx] = d;
+        }
     }
 }
 
@@ -69,6 +88,12 @@ __device__ __forceinline__ double max_f64(double a, double b) {
 __device__ __forceinline__ double chebyshev_f64(double dx, double dy) {  // max(|dx|, |dy|)
     double r;
     asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(dx), "v"(dy));
+    return r;
+}
+
+__device__ __forceinline__ double chebyshev_f64_sx(double dy, double abs_dx_uniform) {  // max(|dy|, s): s in SGPRs
+    double r;
+    asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(dy), "s"(abs_dx_uniform));
     return r;
 }
 
@@ -106,7 +131,7 @@ __device__ __forceinline__ void count_less_batch(const double* tab, int n, int t
 
 // K > 0: the K = k nearest OTHER points are kept in registers (sorted insertion: min/max only).  K == 0: any k,
 // selection by repeated minimum passes.  TI points are processed concurrently per lane.
-template <int K, int TI>
+template <int K, int TI, bool DXT = false>
 __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __restrict__ members,
                                                         const double* __restrict__ prep_px,
                                                         const double* __restrict__ table_psi,
@@ -178,12 +203,34 @@ __global__ __launch_bounds__(64) void mi_kraskov_kernel(const float* const* __re
                     }
                 }
             };
+            if constexpr (DXT) {
+                // x distances from the prepared table (scalar loads; its diagonal excludes the point itself): see
+                // kraskov_direct_kernel
+                const double* dx_col = prep_px + dxt_offset(cs) + i0;
+                const int dxt_cols = (cs + 7) / 8 * 8;
+#pragma unroll 2
+                for (int j = 0; j < cs; j++) {
+                    const double pyj = double(s_y[j * 64 + lane]) + s_nq[j];
+                    const double* dx_row = dx_col + size_t(j) * size_t(dxt_cols);
+#pragma unroll
+                    for (int t = 0; t < TI; t++) {
+                        double d = chebyshev_f64_sx(pyi[t] - pyj, dx_row[t]);
+#pragma unroll
+                        for (int q = 0; q < K; q++) {
+                            const double lo = min_f64(best[t][q], d);
+                            if (q + 1 < K) d = max_f64(best[t][q], d);
+                            best[t][q] = lo;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll 2
             for (int j = 0; j < i0; j++) visit(j, false);
 #pragma unroll 1
             for (int j = i0; j < i1; j++) visit(j, true);
 #pragma unroll 2
             for (int j = i1; j < cs; j++) visit(j, false);
+            }
 #pragma unroll
             for (int t = 0; t < TI; t++) dk[t] = best[t][K - 1];
         } else {
@@ -308,7 +355,7 @@ constexpr int direct_min_waves(int K, int TI, bool SYM) {
     return K <= 2 ? 4 : (K == 3 ? 3 : (K == 4 ? 2 : (K <= 32 ? 3 : 1)));
 }
 
-template <int K, int TI, bool SYM = false>
+template <int K, int TI, bool SYM = false, bool DXT = false>
 __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_direct_kernel(const float* const* __restrict__ members,
                                                             const float* const* __restrict__ members_x,
                                                             const double* __restrict__ prep_px,
@@ -326,6 +373,8 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
     __shared__ int s_nan[16 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));  // uniform: i0 below stays in SGPRs
+    const double* __restrict__ dxt = prep_px + dxt_offset(cs);  // DXT only
+    const int dxt_cols = (cs + 7) / 8 * 8;
     for (int i = threadIdx.x; i < cs; i += 256) {
         s_px[i] = prep_px[i];                         // SYM: noise_ref[i]
         s_spx[i] = SYM ? 0.0 : prep_px[cs + i];
@@ -406,13 +455,23 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                     const int j = j0 + u;
                     const int jc = j < cs ? j : cs - 1;
                     const double pxj = j < cs ? (SYM ? double(xb[SYM ? u : 0]) + s_px[jc] : s_px[jc]) : inf;
-                    const double pyj = j < cs ? double(yb[u]) + s_nq[jc] : inf;
+                    const double pyj = (DXT || j < cs) ? double(yb[u]) + s_nq[jc] : inf;
+                    // DXT: |px_i - px_j| comes from the prepared table through scalar loads -- uniform, so it rides in
+                    // SGPRs as the third operand of the max; the table's diagonal and its rows past the end replace the
+                    // self test and the end test (7 instead of 9 vector instructions per pair for K = 3).  (Requesting
+                    // the row of candidate u + 1 before the pairs of candidate u changed nothing: 26.9 vs 27.0 ms.)
+                    const double* dx_row = DXT ? dxt + size_t(j) * size_t(dxt_cols) + i0 : nullptr;
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
-                        double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
-                        const uint64_t bits = uint64_t(__double_as_longlong(d));
-                        const uint32_t hi = (j == i0 + t) ? 0x7FEFFFFFu : uint32_t(bits >> 32);
-                        d = __longlong_as_double((long long)((uint64_t(hi) << 32) | uint32_t(bits)));
+                        double d;
+                        if constexpr (DXT) {
+                            d = chebyshev_f64_sx(pyi[t] - pyj, dx_row[t]);
+                        } else {
+                            d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
+                            const uint64_t bits = uint64_t(__double_as_longlong(d));
+                            const uint32_t hi = (j == i0 + t) ? 0x7FEFFFFFu : uint32_t(bits >> 32);
+                            d = __longlong_as_double((long long)((uint64_t(hi) << 32) | uint32_t(bits)));
+                        }
 #pragma unroll
                         for (int q = 0; q < K; q++) {
                             const double lo = min_f64(best[t][q], d);
@@ -672,6 +731,8 @@ __global__ __launch_bounds__(64 * NW, sorted_min_waves(K, NS)) void kraskov_sort
                     const int jc = j < cs ? j : cs - 1;
                     const double pxj = j < cs ? s_px[jc] : inf;
                     const double pyj = j < cs ? double(yb[u]) + s_nq[jc] : inf;
+                    // (the scalar-loaded distance table of kraskov_direct_kernel made this kernel slower: 64 members
+                    // k = 3 34.6 vs 31.2 ms at its two waves per SIMD)
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
                         double d = chebyshev_f64(pxi[t] - pxj, pyi[t] - pyj);
@@ -822,7 +883,20 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
                        noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
     // K = k exactly for the small k (the sorted insertion costs 2K - 1 min/max per candidate: K = 4 for k = 3 is 7
     // instead of 5; measured at 256^3 x 64, k = 3: <3, 8> 36.2 ms vs <4, 8> 48.6 ms)
-    if (kk == 1) {
+    // up to 80 members the x distances come from the prepared table (scalar loads)
+    const char* dxt_env = getenv("CRF_KRASKOV_DXT");  // tuning: 0 = compute them per pair
+    const bool use_dxt = cs <= kDxtMaxMembers && !(dxt_env && *dxt_env == '0');
+#define CRF_LAUNCH_DIRECT_DXT(K)                                                                                       \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, 8, false, true>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, \
+                       prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
+    if (use_dxt && kk <= 4) {
+        switch (kk) {
+            case 1: CRF_LAUNCH_DIRECT_DXT(1); break;
+            case 2: CRF_LAUNCH_DIRECT_DXT(2); break;
+            case 3: CRF_LAUNCH_DIRECT_DXT(3); break;
+            default: CRF_LAUNCH_DIRECT_DXT(4); break;
+        }
+    } else if (kk == 1) {
         CRF_LAUNCH_DIRECT(1, 8);
     } else if (kk == 2) {
         CRF_LAUNCH_DIRECT(2, 8);
@@ -842,6 +916,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
         CRF_LAUNCH_DIRECT(128, 1);
     }
 #undef CRF_LAUNCH_DIRECT
+#undef CRF_LAUNCH_DIRECT_DXT
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "kraskov_direct_kernel";
     return hipGetLastError();
@@ -942,12 +1017,12 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // The LDS-tile kernels below are instantiated for k <= 4 and hold a 256*cs-byte column per wave, which caps the
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
-    // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 56 members the
-    // LDS-column kernel with 8 points per sweep wins (its column is small enough for three waves per SIMD: k = 3 at 32 /
-    // 48 / 56 members 8.1 / 16.4 / 23.9 ms vs 8.3 / 16.7 ms tile-free) except for k = 2 from ~44 members on (48 members:
-    // 13.5 vs 14.6 ms).  From 57 members on the column allows two waves only and the tile-free kernel wins (64 members,
-    // k = 1..4: 20.0 / 23.1 / 28.8 / 39.8 ms; 80 members, k = 3: 43.7 ms) -- its four waves share a voxel tile, so its
-    // re-reads stay in L1 / L2 (see the kernel).  k = 4 at 57..64 members goes to the sorted-column kernel (35.0 ms).
+    // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 44 members the
+    // LDS-column kernel with 8 points per sweep wins (three to four waves per SIMD: k = 3 at 32 / 40 / 44 members 7.2 /
+    // 11.6 / 14.7 ms vs 7.8 / 12.8 / 15.2 ms tile-free), for k = 4 up to 56 members (31.6 vs 32.7 ms).  Beyond that the
+    // tile-free kernel with the scalar-loaded x-distance table (k = 3: 48 / 56 / 64 / 80 members 15.3 / 23.0 / 26.8 / 41.8
+    // ms; LDS column 16.4 / 23.9 / - / -) -- its four waves share a voxel tile, so its re-reads stay in L1 / L2 (see the
+    // kernel).  k = 4 at 57..64 members goes to the sorted-column kernel (34.9 vs 37.8 ms).
     const char* sorted = getenv("CRF_KRASKOV_SORTED");  // tuning: 1 = wherever it exists, 0 = never
     if (kk <= 4 && cs <= 64 && !(sorted && *sorted == '0') && !(force_direct && *force_direct == '1') &&
         ((sorted && *sorted == '1') || (cs > 56 && kk == 4))) {
@@ -956,7 +1031,7 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
         if (e != hipErrorNotSupported) return e;
     }
     const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
-    const bool prefer_direct = cs > 56 || (cs > 44 && kk == 2);
+    const bool prefer_direct = cs > 56 || (cs > 44 && kk <= 3);
     if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
         (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
@@ -975,9 +1050,17 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // 16 points per sweep only where the column caps the occupancy at two waves per SIMD anyway (more than 56 members)
     const char* narrow = getenv("CRF_KRASKOV_TI8");  // tuning: 8 points per sweep for every member count
     const bool wide = cs > 56 && (cs % 16 == 0 || cs % 16 > 8) && !(narrow && *narrow == '1');
-#define CRF_LAUNCH_KRASKOV(K, TI)                                                                                     \
-    hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi, noise_query, \
-                       d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
+    // the distance table pays here while it fits the 16 KB scalar cache (256^3, k = 3: 32 members 7.2 vs 8.1 ms; 40
+    // members 12.0 vs 11.6 ms; 48 members 17.3 vs 16.4 ms)
+    const char* dxt_env = getenv("CRF_KRASKOV_DXT");  // tuning: 0 = x distances computed per pair, 1 = table up to 80
+    const bool use_dxt = (dxt_env && *dxt_env == '1') ? cs <= kDxtMaxMembers : (cs <= 32 && !(dxt_env && *dxt_env == '0'));
+#define CRF_LAUNCH_KRASKOV(K, TI)                                                                                        \
+    if (use_dxt && K > 0 && TI <= 8)                                                                                     \
+        hipLaunchKernelGGL((mi_kraskov_kernel<K, TI, (K > 0 && TI <= 8)>), dim3(blocks), dim3(64), lds, s, d_members,    \
+                           prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term);     \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((mi_kraskov_kernel<K, TI>), dim3(blocks), dim3(64), lds, s, d_members, prep, psi,            \
+                           noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term)
     switch (kk) {
         case 1: CRF_LAUNCH_KRASKOV(1, 8); break;
         // 16 points per sweep where the member count fills the last tile well: 253 VGPRs still give the 2 waves per SIMD

@@ -137,12 +137,14 @@ def test_binned_positive_overflow_of_the_bin_index(engine, oracle, cs):
 
 
 @pytest.mark.parametrize("variant", ["CRF_KRASKOV_SORTED", "CRF_KRASKOV_DIRECT", "CRF_KRASKOV_TILE"])
+@pytest.mark.parametrize("dxt", ["0", "1"])
 @pytest.mark.parametrize("cs", [9, 20, 32, 33, 47, 48, 57, 63, 64])
-def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, cs):
+def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, cs):
     """The three Kraskov kernels (sorted-column, tile-free, LDS-column) forced one at a time -- the dispatch picks one per
     (cs, k), so without this a kernel is only exercised where it is the default; the launchers read the variable at
     every call.  Includes a box ensemble (exact ties, resolved by the noise), a NaN voxel and both estimators."""
     monkeypatch.setenv(variant, "1")
+    monkeypatch.setenv("CRF_KRASKOV_DXT", dxt)     # x distances from the prepared table (scalar loads) or per pair
     for k in (1, 2, 3, 4):
         for estimator in (1, 2):
             ens = synth.normal_ensemble(16, 6, 5, cs, seed=70 * cs + k)
@@ -156,6 +158,17 @@ def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, cs):
     expected = {"CRF_KRASKOV_SORTED": "kraskov_sorted_kernel", "CRF_KRASKOV_DIRECT": "kraskov_direct_kernel",
                 "CRF_KRASKOV_TILE": "mi_kraskov_kernel"}[variant]
     assert engine.last_kernel_name() == expected
+
+
+@pytest.mark.parametrize("cs", [65, 72, 79, 80, 81, 88])
+def test_kraskov_distance_table_boundary(engine, oracle, cs):
+    """The x-distance table exists up to 80 members (it shares the 64 KB preparation buffer): both sides of the limit,
+    member counts that are not multiples of the 8-point sweep or the 16-candidate batch."""
+    for k in (1, 3, 4):
+        ens = synth.normal_ensemble(16, 6, 4, cs, seed=5 * cs + k)
+        _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
+               f"KSG-1 cs={cs} k={k}", ref_xyz=(7, 3, 2), k=k, min_identical=0.99)
+    assert engine.last_kernel_name() == "kraskov_direct_kernel"
 
 
 @pytest.mark.parametrize("cs,k", [(16, 2), (64, 3), (100, 5), (64, 12), (100, 40), (160, 70)])
