@@ -470,7 +470,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
                     key[g] = composite_key(b[p]);
                     if (p > 0) tie_min = min(tie_min, key[g] ^ prev);
                     if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
-                    if (p == CHB - 1) is_nan |= key[g] > 0xFF800000u;  // (guarded batch taken: nB == CHB)
+                    // the largest key of the voxel sits at position nB - 1 (CHB - 1 in the exact instantiation)
+                    if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
                     prev = key[g];
                 }
                 lower_bound_col_batch<CH, G>(&lds[lane], key, tie_min, less);  // #{A < b_p}, 0..CH
