@@ -1045,7 +1045,8 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     if (ref.prepare()) launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
     if (!ref.run()) return hipGetLastError();
     const unsigned blocks = unsigned((num_voxels + 63) / 64);
-    const size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
+    size_t lds = size_t(4 * cs + 1 + ((cs + 1) & 1)) * sizeof(double) + size_t(cs) * 64 * sizeof(float);
+    if (const char* pad = getenv("CRF_KRASKOV_LDS_PAD")) lds += size_t(atoi(pad));  // tuning: occupancy experiments
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
     // 16 points per sweep only where the column caps the occupancy at two waves per SIMD anyway (more than 56 members)
     const char* narrow = getenv("CRF_KRASKOV_TI8");  // tuning: 8 points per sweep for every member count

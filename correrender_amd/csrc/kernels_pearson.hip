@@ -399,6 +399,143 @@ __device__ __forceinline__ void load_chunk_64(const float* const* __restrict__ m
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 385..512 members, one HBM read (r02): a block of 8 waves holds ONE 64-voxel tile, wave w keeps members
+// [64 w, 64 w + 64) of it in registers.  The three passes of computePearson2<float> are sequential fp32 sums over the
+// members, so a pass runs as a relay: wave 0 adds its 64 terms, hands the running value to wave 1 through LDS, ... --
+// 8 stages per pass, a barrier between stages; what does not lie on the chain (deviations, quotients) is computed by
+// all waves at once between the passes.  Same operations in the same order as the reference, every member value
+// fetched once (pearson_big_kernel reads the volume three times: 3.0x the algorithmic bytes at the fabric counters).
+// Only one wave of a block works during a stage, and a lone wave issues a dependent fp32 chain slowly: the kernel is
+// bound by that latency, not by HBM -- 256x256x64: 385 / 512 members 2.72 / 2.91 ms (3.0 TB/s at 512) against 3.37 /
+// 4.39 ms for the three-pass kernel.  Two blocks per CU (128-register cap) overlap one block's loads with the other's
+// relay: 0.72 vs 1.68 ms at 128x128x64 x 400 with 143 registers and one block per CU.  With 128 members per wave
+// (513..1024 members) the relay loses to the three-pass kernel (2.40 vs 2.22 ms at 1000 members): not instantiated.
+// ---------------------------------------------------------------------------------------------------------
+template <int W, int R>
+__global__ __launch_bounds__(64 * W, 4)  // 4 waves per SIMD: 128 registers, two blocks per CU
+    void pearson_relay_kernel(const float* const* __restrict__ members,
+                                                               const float* __restrict__ prep,
+                                                               float* __restrict__ out, uint32_t num_voxels, int cs) {
+    // The products of a pass do not depend on the relay stage, so the compiler would hoist all R of them in front of the
+    // relay (R more registers; the 128-register cap then spills).  The scale factor is laundered through an empty asm
+    // inside the stage, which pins the products there.
+    constexpr bool kPinned = true;
+    __shared__ float s_relay[64];
+    const int lane = int(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int e0 = wave * R;
+    const uint32_t bytes = num_voxels * 4u;
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    const uint32_t tiles = (num_voxels + 63u) / 64u;
+    // this wave's member pointers and a_e, one per lane and group of 64 members (handed out with v_readlane)
+    constexpr int G = R / 64;
+    uint32_t ptr_lo[G], ptr_hi[G];
+    float a_mine[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int e = e0 + g * 64 + lane;
+        const uint64_t ptr = reinterpret_cast<uint64_t>(members[e < cs ? e : cs - 1]);
+        ptr_lo[g] = uint32_t(ptr);
+        ptr_hi[g] = uint32_t(ptr >> 32);
+        a_mine[g] = e < cs ? prep[e] : 0.0f;
+    }
+#pragma unroll 1
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint32_t v0 = t * 64u + uint32_t(lane);
+        const uint32_t byte_offset = v0 * 4u;  // lanes past the end read 0 and store nothing
+        // (the member-count tests `e0 + i < cs` are uniform; left alone the compiler evaluates all R of them once, keeps
+        // them as SGPR pairs across the tile loop and spills those to VGPR lanes: the count is laundered per phase)
+        int cs_p = cs;
+        asm volatile("" : "+s"(cs_p));
+        float y[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const uint64_t base = (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_hi[i / 64]), i % 64))) << 32) |
+                                  uint64_t(uint32_t(__builtin_amdgcn_readlane(int(ptr_lo[i / 64]), i % 64)));
+            y[i] = load_member_nt(reinterpret_cast<const float*>(base), bytes,
+                                  e0 + i < cs_p ? byte_offset : kOutOfRangeOffset);  // a slot past cs reads 0
+        }
+        // ---- pass 1: meanY += invN * y_e
+#pragma unroll 1
+        for (int s = 0; s < W; s++) {
+            if (wave == s) {
+                float m = s == 0 ? 0.0f : s_relay[lane];
+                float scale = invN;
+                if constexpr (kPinned) asm volatile("" : "+v"(scale));
+#pragma unroll
+                for (int i = 0; i < R; i++) m += scale * y[i];  // a padded slot adds invN * 0 = +0
+                s_relay[lane] = m;
+            }
+            __syncthreads();
+        }
+        const float meanY = s_relay[lane];
+        __syncthreads();
+        asm volatile("" : "+s"(cs_p));
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            y[i] = e0 + i < cs_p ? y[i] - meanY : 0.0f;
+            if (kPinned && (i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // in place, 8 at a time: register pressure
+        }
+        // ---- pass 2: varY += invNm1 * d * d
+#pragma unroll 1
+        for (int s = 0; s < W; s++) {
+            if (wave == s) {
+                float var = s == 0 ? 0.0f : s_relay[lane];
+                float scale = invNm1;
+                if constexpr (kPinned) asm volatile("" : "+v"(scale));
+#pragma unroll
+                for (int i = 0; i < R; i++) var += scale * y[i] * y[i];
+                s_relay[lane] = var;
+            }
+            __syncthreads();
+        }
+        const float sdY = sqrtf(s_relay[lane]);
+        __syncthreads();
+        if (__all(exact_div_guard(meanY, sdY))) {  // the same lanes in every wave of the block: one decision
+            const float rcp = 1.0f / sdY;
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                y[i] = exact_div(y[i], sdY, rcp);
+                if (kPinned && (i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            asm volatile("" : "+s"(cs_p));
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                y[i] = e0 + i < cs_p ? y[i] / sdY : 0.0f;
+                if (kPinned && (i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- pass 3: r += a_e * ((y_e - meanY) / sdY)
+#pragma unroll 1
+        for (int s = 0; s < W; s++) {
+            if (wave == s) {
+                float r = s == 0 ? 0.0f : s_relay[lane];
+                asm volatile("" : "+s"(cs_p));
+                float a_lanes[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    a_lanes[g] = a_mine[g];
+                    if constexpr (kPinned) asm volatile("" : "+v"(a_lanes[g]));
+                }
+#pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const float a =
+                        __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(a_lanes[i / 64])), i % 64)));
+                    if (e0 + i < cs_p) r += a * y[i];
+                }
+                s_relay[lane] = r;
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && v0 < num_voxels) store_result_nt(out + v0, s_relay[lane]);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64) void pearson_big_kernel(const float* const* __restrict__ members,
                                                          const float* __restrict__ prep, float* __restrict__ out,
                                                          uint32_t num_voxels, int cs) {
@@ -720,7 +857,20 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
     } else {
         // chunked three-pass kernel (see pearson_big_kernel); CRF_PEARSON_BIG=0 selects the plain streaming kernel,
         // CRF_PEARSON_BIG_WAVES overrides the grid (tuning)
-        if (env_int("CRF_PEARSON_BIG", 1) != 0) {
+        if (cs <= 512 && env_int("CRF_PEARSON_RELAY", 1) != 0) {
+            // one block per 64-voxel tile at a time, as many blocks as the chip holds
+            const size_t tiles = (num_voxels + 63) / 64;
+            int per_cu = 1, device = 0, cus = 256;
+            (void)hipGetDevice(&device);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pearson_relay_kernel<8, 64>, 512, 0);
+            const size_t want = size_t(cus) * size_t(per_cu > 0 ? per_cu : 1);
+            const unsigned blocks = unsigned(tiles < want ? tiles : want);
+            hipLaunchKernelGGL((pearson_relay_kernel<8, 64>), dim3(blocks), dim3(512), 0, s, d_members, d_prep, d_out,
+                               uint32_t(num_voxels), cs);
+            covered = num_voxels;
+            if (info) info->kernel_name = "pearson_relay_kernel";
+        } else if (env_int("CRF_PEARSON_BIG", 1) != 0) {
             const size_t tiles = (num_voxels + 63) / 64;
             const size_t want = size_t(env_int("CRF_PEARSON_BIG_WAVES", kBigWaves));
             const unsigned blocks = unsigned(tiles < want ? tiles : want);

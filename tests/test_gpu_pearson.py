@@ -22,7 +22,8 @@ def _run(engine, oracle, ens, ref_xyz):
 
 
 @pytest.mark.parametrize("cs", [2, 3, 8, 9, 16, 17, 31, 32, 33, 48, 56, 64, 65, 72, 80, 96, 100, 112, 128, 130, 150, 160,
-                                192, 200, 224, 250, 256, 257, 300, 320, 383, 384, 385, 450, 700])
+                                192, 200, 224, 250, 256, 257, 300, 320, 383, 384, 385, 450, 511, 512, 513, 577, 700, 1000,
+                                1023, 1024, 1025, 1100])
 def test_pearson_member_counts(engine, oracle, cs):
     # 20*12*9 = 2160 voxels: not a multiple of any block size -> exercises the ragged tail as well
     ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
@@ -99,7 +100,7 @@ def test_pearson_device_path_matches_host_path(engine, oracle):
     assert bit_identical(out.cpu().numpy(), want).all()
 
 
-@pytest.mark.parametrize("cs", [16, 64, 100, 200])
+@pytest.mark.parametrize("cs", [16, 64, 100, 200, 400, 600])
 def test_pearson_magnitude_sweep_bit_exact(engine, oracle, cs):
     """Every voxel gets its own scale and offset over 50 decades, so the per-voxel quotient (y - mean) / sd is taken at
     standard deviations and means on both sides of the exact-division guard (crf_device.h: sd in [2^-60, 2^60],
