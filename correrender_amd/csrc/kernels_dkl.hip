@@ -74,6 +74,42 @@ struct KnnWindow {
     __device__ float cost(int lo) const { return fmaxf(left_gap(lo), right_gap(lo + k)); }
 };
 
+// The same descent for E sorted elements at once (e0 .. e0 + E - 1, clamped to the column): the step sequence depends
+// on k only, so the rounds are the outer loop and the E x 6 column reads of a round are independent -- one element after
+// the other, every round was a dependent LDS round trip (r02: the kernel is bound by exactly that latency).
+template <int E>
+__device__ __forceinline__ void dkl_window_distances(const float* data, int N, int k, int e0, float (&dist)[E]) {
+    KnnWindow w[E];
+    int lo[E];
+    const int first_step = (k + 1) / 2;
+#pragma unroll
+    for (int u = 0; u < E; u++) {
+        const int i = e0 + u < N ? e0 + u : N - 1;
+        w[u] = KnnWindow{data, N, k, i, data[i * 64]};
+        lo[u] = i - first_step > 0 ? i - first_step : 0;
+        lo[u] = lo[u] + k >= N ? N - k - 1 : lo[u];
+    }
+    int step = first_step;
+#pragma unroll 1
+    for (bool last = false; !last; step = (step + 1) / 2) {
+        last = step == 1;
+        float here[E], left[E], right[E];
+#pragma unroll
+        for (int u = 0; u < E; u++) {
+            here[u] = w[u].cost(lo[u]);
+            left[u] = w[u].cost(lo[u] - step);
+            right[u] = w[u].cost(lo[u] + step);
+        }
+#pragma unroll
+        for (int u = 0; u < E; u++) {
+            const int towards = (left[u] > right[u]) - (left[u] < right[u]);
+            lo[u] += (here[u] < left[u] && here[u] < right[u]) ? 0 : towards * step;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < E; u++) dist[u] = w[u].cost(lo[u]);
+}
+
 __device__ float dkl_window_distance(const float* data, int N, int k, int i) {
     const KnnWindow w{data, N, k, i, data[i * 64]};
     int step = (k + 1) / 2;
@@ -135,18 +171,45 @@ __global__ __launch_bounds__(64, (NS > 0 && NS <= 64) ? 2 : 1) void dkl_kernel(c
         const uint32_t byte_offset = active ? uint32_t(v) * 4u : kOutOfRangeOffset;
         bool is_nan = false;
         double mean = 0.0;
-#pragma unroll 4
-        for (int e = 0; e < cs; e++) {
-            const float x = load_member_nt(members[e], bytes, byte_offset);
-            is_nan |= x != x;
-            vals[e * 64] = x;
-            mean += factor * double(x);
-        }
         double variance = 0.0;
+        // network instantiations (k-NN estimator, cs <= NS <= 128): the voxel's values stay in registers from the load
+        // to the sorted column -- the passes over the LDS column were one dependent LDS round trip per 2-4 members each
+        float x[NS > 0 ? NS : 1];
+        if constexpr (NS > 0) {
+            int cs_p = cs;  // (laundered per phase: keeps the compiler from carrying NS uniform member-count tests as
+            asm volatile("" : "+s"(cs_p));  // SGPR pairs across the persistent tile loop)
+#pragma unroll
+            for (int e = 0; e < NS; e++)
+                x[e] = load_member_nt(members[e < cs_p ? e : cs_p - 1], bytes, e < cs_p ? byte_offset : kOutOfRangeOffset);
+            asm volatile("" : "+s"(cs_p));
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                if (e < cs_p) {
+                    is_nan |= x[e] != x[e];
+                    mean += factor * double(x[e]);
+                }
+            }
+            asm volatile("" : "+s"(cs_p));
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                if (e < cs_p) {
+                    const double diff = mean - double(x[e]);
+                    variance += factor * diff * diff;
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int e = 0; e < cs; e++) {
+                const float xe = load_member_nt(members[e], bytes, byte_offset);
+                is_nan |= xe != xe;
+                vals[e * 64] = xe;
+                mean += factor * double(xe);
+            }
 #pragma unroll 2
-        for (int e = 0; e < cs; e++) {
-            const double diff = mean - double(vals[e * 64]);
-            variance += factor * diff * diff;
+            for (int e = 0; e < cs; e++) {
+                const double diff = mean - double(vals[e * 64]);
+                variance += factor * diff * diff;
+            }
         }
         const double stdev = sqrt(variance);
         // (v - mean) / stdev for the cs members of the voxel: ONE division (the reciprocal) per voxel, the quotients
@@ -210,17 +273,90 @@ __global__ __launch_bounds__(64, (NS > 0 && NS <= 64) ? 2 : 1) void dkl_kernel(c
             res = (overflow || isinf(dkl)) ? qnan : float(dkl);
         } else {
             bool any_nan = false;
+            if constexpr (NS == 0) {
 #pragma unroll 2
-            for (int e = 0; e < cs; e++) {
-                const float val = float(normalised(double(vals[e * 64]) - mean));
-                any_nan |= val != val;
-                vals[e * 64] = val;
+                for (int e = 0; e < cs; e++) {
+                    const float val = float(normalised(double(vals[e * 64]) - mean));
+                    any_nan |= val != val;
+                    vals[e * 64] = val;
+                }
             }
             // ascending sort of the lane's column: up to 128 members through a register min/max network on
             // order-preserving 32-bit keys (r02; the estimator only reads the sorted VALUES, so the order among equal
             // values is immaterial; with a NaN the result is NaN whatever the column holds), beyond that by counting
             if constexpr (NS > 0) {
-                sort_column<NS>(vals, sorted, cs);
+                // normalise, map to order-preserving keys (pads behind every real value), sort, park the sorted VALUES
+                uint32_t a[NS];
+                int cs_p = cs;
+                asm volatile("" : "+s"(cs_p));
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    const float val = float(normalised(double(x[e]) - mean));
+                    any_nan |= (e < cs_p) && (val != val);
+                    a[e] = e < cs_p ? orderable_key(val) : 0xFFFFFFFFu;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                SortNet32<NS>::sort(a);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+s"(cs_p));
+                if (NS <= 96 && k <= 2 && cs >= 4) {  // (NS = 112, 128: scratch)
+                    // k = 1, 2: the descent is ONE round with step 1 (see KnnWindow), so the window it ends in is the
+                    // start window or a neighbour, all within [i - 3, i + 3] of element i: with the sorted values in
+                    // registers and i a compile-time index nothing is read from LDS at all.  c[m] = cost of the window
+                    // that starts at i + m; the start window is i - 1 (0 for i = 0; i - 2 for k = 2 at the last
+                    // element), chosen by wave-uniform selects.  Same comparisons as dkl_window_distance().
+                    float sv[NS];
+#pragma unroll
+                    for (int p = 0; p < NS; p++) {
+                        const uint32_t key = a[p];
+                        sv[p] = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+                    }
+                    const float big = 3.402823466e+38f;
+                    double second_moment = 0.0, mant_prod = 1.0;
+                    int exp_sum = 0;
+#pragma unroll
+                    for (int i = 0; i < NS; i++) {
+                        if (i < cs_p) {
+                            const float centre = sv[i];
+                            float c[5];  // m = -3 .. +1
+#pragma unroll
+                            for (int m = -3; m <= 1; m++) {
+                                const int lo = i + m;
+                                // left_gap(lo): lo in [0, i]; right_gap(lo + k): lo + k in [i, n)
+                                const float left = (lo >= 0 && lo <= i) ? centre - sv[lo >= 0 && lo < NS ? lo : 0] : big;
+                                const int h1 = lo + 1, h2 = lo + 2;
+                                const float r1 = (h1 >= i && h1 < NS && h1 < cs_p) ? sv[h1 >= 0 && h1 < NS ? h1 : 0] - centre : big;
+                                const float r2 = (h2 >= i && h2 < NS && h2 < cs_p) ? sv[h2 >= 0 && h2 < NS ? h2 : 0] - centre : big;
+                                c[m + 3] = fmaxf(left, k == 2 ? r2 : r1);
+                            }
+                            int lo0 = i - 1 > 0 ? i - 1 : 0;
+                            lo0 = lo0 + k >= cs_p ? cs_p - k - 1 : lo0;
+                            const int d0 = lo0 - i;  // -1; 0 for i = 0; -2 for k = 2 at the last element
+                            const float here = d0 == -1 ? c[2] : (d0 == 0 ? c[3] : c[1]);
+                            const float left = d0 == -1 ? c[1] : (d0 == 0 ? c[2] : c[0]);
+                            const float right = d0 == -1 ? c[3] : (d0 == 0 ? c[4] : c[2]);
+                            const int towards = (left > right) - (left < right);
+                            const bool stay = here < left && here < right;
+                            const float dist = stay ? here : (towards > 0 ? right : (towards < 0 ? left : here));
+                            int xp;
+                            mant_prod *= __builtin_frexp(double(dist), &xp);
+                            exp_sum += xp;
+                            second_moment += factor * double(centre) * double(centre);
+                        }
+                    }
+                    const double entropy = factor * (log(mant_prod) + 0.693147180559945309417 * double(exp_sum)) + knn_const;
+                    const float dkl = float(-entropy + half_log_two_pi + 0.5 * second_moment);
+                    res = isinf(dkl) ? qnan : ((dkl < 0.0f) ? 0.0f : dkl);
+                    if (any_nan || is_nan) res = qnan;
+                    if (active) store_result_nt(out + v, res);
+                    continue;
+                }
+#pragma unroll
+                for (int p = 0; p < NS; p++) {
+                    const uint32_t key = a[p];
+                    const uint32_t bits = (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key;
+                    if (p < cs_p) sorted[p * 64] = __uint_as_float(bits);
+                }
             } else {
 #pragma unroll 1
                 for (int e = 0; e < cs; e++) {  // position = #{smaller} + #{equal with a lower index}
@@ -234,15 +370,34 @@ __global__ __launch_bounds__(64, (NS > 0 && NS <= 64) ? 2 : 1) void dkl_kernel(c
                     sorted[(any_nan ? e : pos) * 64] = ve;
                 }
             }
-            double entropy = 0.0, second_moment = 0.0;
+            // sum_e ln(d_e) as ONE logarithm: d_e = m_e * 2^x_e (frexp), sum = ln(prod m_e) + ln 2 * sum x_e.  The product
+            // of up to 256 mantissas in [0.5, 1) stays a normal double and carries ~256 ulp of relative error -- 1e-14
+            // against the 1e-5 tolerance of this float-valued estimator; a zero distance gives ln 0 = -inf, an infinite
+            // or NaN one propagates, as with one logarithm per element (which was ~100 fp64 instructions each).
+            double second_moment = 0.0, log_sum = 0.0, mant_prod = 1.0;
+            int exp_sum = 0;
+            constexpr int E = 4;  // elements per descent batch
 #pragma unroll 1
-            for (int e = 0; e < cs; e++) {
-                const double nn_dist = double(dkl_window_distance(sorted, cs, k, e));
-                entropy += factor * log(nn_dist);
-                const double value = double(sorted[e * 64]);
-                second_moment += factor * value * value;
+            for (int e0 = 0; e0 < cs; e0 += E) {
+                float dist[E];
+                dkl_window_distances<E>(sorted, cs, k, e0, dist);
+#pragma unroll
+                for (int u = 0; u < E; u++) {  // member order
+                    if (e0 + u < cs) {
+                        int x;
+                        mant_prod *= __builtin_frexp(double(dist[u]), &x);
+                        exp_sum += x;
+                        const double value = double(sorted[(e0 + u) * 64]);
+                        second_moment += factor * value * value;
+                    }
+                }
+                if ((e0 & 255) == 256 - E || e0 + E >= cs) {  // fold the product every 256 elements and at the end
+                    log_sum += log(mant_prod) + 0.693147180559945309417 * double(exp_sum);
+                    mant_prod = 1.0;
+                    exp_sum = 0;
+                }
             }
-            entropy += knn_const;
+            double entropy = factor * log_sum + knn_const;
             const float dkl = float(-entropy + half_log_two_pi + 0.5 * second_moment);
             res = isinf(dkl) ? qnan : ((dkl < 0.0f) ? 0.0f : dkl);  // std::max(dkl, 0.0f): NaN stays NaN
             if (any_nan) res = qnan;
@@ -260,7 +415,10 @@ hipError_t launch_dkl(const float* const* d_members, int cs, size_t num_voxels, 
     unsigned blocks = unsigned(tiles < size_t(kDklBlocks) ? tiles : size_t(kDklBlocks));
     const char* counting = getenv("CRF_DKL_COUNTING_SORT");  // tuning / tests: the O(cs^2) column sort for every cs
     const bool network_sort = estimator == 1 && cs <= 128 && !(counting && *counting == '1');
-    const size_t tile = dkl_tile_bytes(cs, estimator, num_bins, network_sort);
+    // k-NN with k <= 2 up to 96 members runs entirely in registers (see the kernel): no LDS column, so the occupancy is
+    // the registers' alone
+    const bool register_descent = network_sort && k <= 2 && cs >= 4 && cs <= 96;
+    const size_t tile = register_descent ? 0 : dkl_tile_bytes(cs, estimator, num_bins, network_sort);
     const bool use_lds = tile <= kDklLdsLimit;  // (one column of <= 128 members always fits)
     if (!use_lds && !d_workspace) return hipErrorInvalidValue;
     const size_t lds_bytes = dkl_log_table_bytes(cs, estimator) + (use_lds ? tile : 0);

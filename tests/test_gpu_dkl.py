@@ -53,21 +53,27 @@ def test_gpu_dkl_binned(engine, oracle, cs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cs", [2, 16, 50, 64, 128, 300])
+@pytest.mark.parametrize("cs", [2, 3, 4, 5, 16, 17, 33, 50, 64, 80, 96, 97, 128, 300])
 def test_gpu_dkl_knn(engine, oracle, cs):
     ens = _ensemble(cs, 20 + cs)
     _, zs, ys, xs = ens.shape
     engine.set_grid(xs, ys, zs, cs)
     engine.upload_members(ens)
-    for k in sorted({1, max(1, -(-3 * cs // 100)), min(cs - 1, 7)}):
+    # k = 1, 2 up to 96 members: the register form of the window descent; larger k / member counts: the LDS column
+    for k in sorted({1, min(2, cs - 1), max(1, -(-3 * cs // 100)), min(cs - 1, 7)}):
         got = engine.dkl("knn", k=k)
         want = oracle.dkl(1, ens, k=k)
         assert_close(got, want, f"DKL k-NN cs={cs} k={k}")
         assert bit_identical(got, want).mean() > 0.98
     g = got.reshape(zs, ys, xs)
     assert np.isnan(g[0, 0, 2]) and np.isnan(g[0, 0, 3])
-    if cs >= 16:
+    w = want.reshape(zs, ys, xs)
+    assert np.isnan(g[0, 0, 4]) == np.isnan(w[0, 0, 4])
+    if cs in (16, 50, 64, 128, 300):
         assert np.isnan(g[0, 0, 4])                            # duplicate values -> log(0) -> inf -> NaN (DKL.cpp:158-160)
+    # and with k = 1 every voxel of rounded values has a zero nearest-neighbour distance
+    if cs >= 16:
+        assert np.isnan(engine.dkl("knn", k=1).reshape(zs, ys, xs)[0, 0, 4])
 
 
 @pytest.mark.gpu
