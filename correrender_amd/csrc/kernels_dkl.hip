@@ -227,7 +227,64 @@ __global__ __launch_bounds__(64, (NS > 0 && NS <= 64) ? 2 : 1) void dkl_kernel(c
             return a / stdev;
         };
         float res;
-        if (estimator == 0) {
+        if (NS > 0 && NS <= 96 && estimator == 0) {
+            // Binned estimator, up to 96 members, all in registers: the samples' bin indices are sorted with the
+            // min/max network and the histogram is read off as run lengths (the form of mi_binned_kernel) -- no LDS
+            // column, no element-by-element read-modify-write of an LDS histogram.  Runs come out in ascending bin
+            // order, the order of the reference's loop over the bins, so the sum is the same sum.
+            if constexpr (NS > 0 && NS <= 96) {
+                int cs_p = cs;
+                asm volatile("" : "+s"(cs_p));
+                double min_val = 1.7976931348623157e308, max_val = -1.7976931348623157e308;
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    if (e < cs_p) {
+                        const double val = normalised(double(x[e]) - mean);
+                        x[e] = float(val);
+                        min_val = (val < min_val) ? val : min_val;  // a NaN never replaces the extremum
+                        max_val = (max_val < val) ? val : max_val;
+                    }
+                }
+                min_val -= 0.01;
+                max_val += 0.01;
+                const double bin_factor = double(num_bins) / (max_val - min_val);
+                const double bin_factor_inv = (max_val - min_val) / double(num_bins);
+                uint32_t a[NS];
+                asm volatile("" : "+s"(cs_p));
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    const double tt = (double(x[e]) - min_val) * bin_factor;
+                    int b = (tt > -2147483649.0 && tt < 2147483648.0) ? int(tt) : 0;  // x86 int(): see below
+                    b = b < 0 ? 0 : (b > num_bins - 1 ? num_bins - 1 : b);
+                    a[e] = e < cs_p ? uint32_t(b) : 0xFFFFFFFFu;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                SortNet32<NS>::sort(a);
+                __builtin_amdgcn_sched_barrier(0);
+                const double gauss_norm = sqrt(0.5 / double(kSglPi));
+                const double log_scale = log(bin_factor / (double(cs) * gauss_norm));
+                double dkl = 0.0;
+                bool overflow = false;
+                uint32_t run = 0;  // samples of the current bin seen so far
+                asm volatile("" : "+s"(cs_p));
+#pragma unroll
+                for (int p = 0; p < NS; p++) {
+                    if (p < cs_p) {
+                        run += 1u;
+                        const bool last_of_bin = (p + 1 < NS) ? (p + 1 >= cs_p || a[p + 1 < NS ? p + 1 : p] != a[p]) : true;
+                        const uint32_t h = last_of_bin ? run : 0u;
+                        const double px = double(h) / double(cs);
+                        const double center = (double(a[p]) + 0.5) * bin_factor_inv + min_val;
+                        const double half_sq = 0.5 * (center * center);
+                        overflow |= last_of_bin && half_sq > 745.1332191019411;
+                        const double term = (s_logn[h] + log_scale + half_sq) * px;
+                        dkl = last_of_bin ? dkl + term : dkl;
+                        run = last_of_bin ? 0u : run;
+                    }
+                }
+                res = (overflow || isinf(dkl)) ? qnan : float(dkl);
+            }
+        } else if (estimator == 0) {
             double min_val = 1.7976931348623157e308, max_val = -1.7976931348623157e308;
 #pragma unroll 2
             for (int e = 0; e < cs; e++) {
@@ -414,11 +471,14 @@ hipError_t launch_dkl(const float* const* d_members, int cs, size_t num_voxels, 
     const size_t tiles = (num_voxels + 63) / 64;
     unsigned blocks = unsigned(tiles < size_t(kDklBlocks) ? tiles : size_t(kDklBlocks));
     const char* counting = getenv("CRF_DKL_COUNTING_SORT");  // tuning / tests: the O(cs^2) column sort for every cs
-    const bool network_sort = estimator == 1 && cs <= 128 && !(counting && *counting == '1');
+    const bool plain = counting && *counting == '1';
+    // network instantiations: the k-NN estimator up to 128 members, the binned estimator up to 96 (registers only)
+    const bool binned_registers = estimator == 0 && cs <= 96 && !plain;
+    const bool network_sort = (estimator == 1 && cs <= 128 && !plain) || binned_registers;
     // k-NN with k <= 2 up to 96 members runs entirely in registers (see the kernel): no LDS column, so the occupancy is
     // the registers' alone
-    const bool register_descent = network_sort && k <= 2 && cs >= 4 && cs <= 96;
-    const size_t tile = register_descent ? 0 : dkl_tile_bytes(cs, estimator, num_bins, network_sort);
+    const bool register_descent = estimator == 1 && network_sort && k <= 2 && cs >= 4 && cs <= 96;
+    const size_t tile = (register_descent || binned_registers) ? 0 : dkl_tile_bytes(cs, estimator, num_bins, network_sort);
     const bool use_lds = tile <= kDklLdsLimit;  // (one column of <= 128 members always fits)
     if (!use_lds && !d_workspace) return hipErrorInvalidValue;
     const size_t lds_bytes = dkl_log_table_bytes(cs, estimator) + (use_lds ? tile : 0);

@@ -35,13 +35,13 @@ def test_oracle_dkl_matches_theory(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cs", [2, 16, 50, 64, 128, 300])
+@pytest.mark.parametrize("cs", [2, 3, 16, 17, 33, 50, 64, 80, 96, 97, 128, 300])   # up to 96: the register form
 def test_gpu_dkl_binned(engine, oracle, cs):
     ens = _ensemble(cs, 10 + cs)
     _, zs, ys, xs = ens.shape
     engine.set_grid(xs, ys, zs, cs)
     engine.upload_members(ens)
-    for bins in (10, 80):
+    for bins in (10, 80, 300):
         got = engine.dkl("binned", num_bins=bins)
         want = oracle.dkl(0, ens, num_bins=bins)
         assert_close(got, want, f"DKL binned cs={cs} bins={bins}")
