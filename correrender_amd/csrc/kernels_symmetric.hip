@@ -145,6 +145,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_symmetric_kernel(const
     __builtin_amdgcn_sched_barrier(0);
 
     // computePearson2<float>(ranksX, ranksY, cs), sequential fp32, member order; pads contribute +0
+    // (N > 64: reading the ranks back from LDS in three rolled passes instead of holding 2N floats was measured and is
+    // not faster -- 100 members 11.1 vs 9.4 ms, 128 members 11.8 vs 11.2 ms: the registers are the sort's, not the tail's)
     float rx[N], ry[N];
 #pragma unroll
     for (int e = 0; e < N; e++) {
@@ -194,6 +196,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
                                                                           float* __restrict__ out, size_t num_voxels,
                                                                           int cs, size_t num_items, RequestArgs ra) {
     __shared__ uint16_t xinfo[N * 64];  // [member][lane]: position in the X order | last position of its X-tie group << 8
+    // N > 64: the Y order as a second column, [position][lane]: member | (same Y as the previous position) << 8
+    constexpr bool kRolledWalk = N > 64;
+    __shared__ uint16_t yseq[kRolledWalk ? N * 64 : 64];
     constexpr int SURE = sure_slots<N>();
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
@@ -253,6 +258,48 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
     int32_t discordant = 0, n2 = 0, run = 0;
     uint32_t prev_key = 0;
     uint32_t info[8];
+    if constexpr (kRolledWalk) {
+        // More than 64 members: the 2N registers of the sorted composites leave no room for an unrolled walk (r01: every
+        // look-up and mask hoisted, 1-2 KB of scratch per lane, 19 / 27 ms at 100 / 128 members).  The Y order goes to
+        // LDS instead -- member and tie flag per position -- and the walk is a rolled loop over the two columns with a
+        // handful of registers; the tie runs of Y are still counted on the sorted keys here.
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            const uint32_t key = composite_key(b[p]);
+            const bool same = p > 0 && key == prev_key;
+            if (p > 0) {
+                run = ((EXACT || p < SURE || p < cs) && same) ? run + 1 : 0;  // ties in Y: t(t-1)/2 per run
+                n2 += run;
+            }
+            prev_key = key;
+            yseq[p * 64 + lane] = uint16_t((composite_low(b[p]) & 0xFFu) | (same ? 0x100u : 0u));
+            if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int p0 = 0; p0 < N; p0 += 8) {
+            uint32_t ys[8], xi[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) ys[q] = yseq[(p0 + q) * 64 + lane];  // two levels of independent reads
+#pragma unroll
+            for (int q = 0; q < 8; q++) xi[q] = xinfo[(ys[q] & 0xFFu) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const bool same = (ys[q] & 0x100u) != 0u;
+                const uint32_t slot = xi[q] & 0xFFu, g = xi[q] >> 8;
+                const uint64_t gm = 0xFFFFFFFFFFFFFFFEull << (g & 63u);
+                const uint64_t sbit = 1ull << (slot & 63u);
+#pragma unroll
+                for (int w = 0; w < W; w++) {
+                    seen[w] |= same ? 0ull : pending[w];
+                    pending[w] = same ? pending[w] : 0ull;
+                    const uint64_t mask = (uint32_t(w) > (g >> 6)) ? ~0ull : ((uint32_t(w) == (g >> 6)) ? gm : 0ull);
+                    discordant += __popcll(seen[w] & mask);
+                    pending[w] |= (uint32_t(w) == (slot >> 6)) ? sbit : 0ull;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < N; p++) {
         const uint32_t key = composite_key(b[p]);
@@ -297,6 +344,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_symmetric_kernel(const 
             }
         }
         if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
