@@ -77,6 +77,24 @@ __device__ __forceinline__ bool rank_side(const float* const* __restrict__ membe
     SortNet<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
     const bool is_nan = sorted_keys_hold_nan<N, EXACT>(a, cs);
+    // Tie-free fast path (as in spearman_kernel): when no lane of the wave has two equal values among its members,
+    // 2 * rank = 2 * position + 2 and the two tie-run scans (~8 vector instructions per element) are skipped.  Pads are
+    // left out of the test (they tie with each other) and their rank slots are never read as ranks.
+    {
+        constexpr int SURE = sure_slots<N>();
+        uint32_t tie_min = 0xFFFFFFFFu;  // min over neighbouring members of (key ^ previous key): 0 iff a tie
+#pragma unroll
+        for (int p = 1; p < N; p++) {
+            const uint32_t x = composite_key(a[p]) ^ composite_key(a[p - 1]);
+            tie_min = min(tie_min, (EXACT || p < SURE || p < cs) ? x : 0xFFFFFFFFu);
+        }
+        if (!__any(tie_min == 0u)) {
+#pragma unroll
+            for (int p = 0; p < N; p++)
+                if (EXACT || p < SURE || p < cs) rank2[(composite_low(a[p]) & 0xFFu) * 64] = uint16_t(2 * p + 2);
+            return is_nan;
+        }
+    }
     uint32_t run_start = 0;  // forward scan: first position of the tie run, parked in bits 8..15 of the low word
 #pragma unroll
     for (int p = 0; p < N; p++) {
