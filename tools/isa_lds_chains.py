@@ -36,7 +36,7 @@ def main():
                 pending = 0
         elif t.startswith("s_cbranch"):
             loops += 1
-        elif t.startswith("s_endpgm"):
+        elif t.startswith(".Lfunc_end"):  # (not s_endpgm: a kernel with an early return has several)
             if want in name:
                 rows.append((name, valu, reads, waits, loops))
             name = None
