@@ -629,27 +629,38 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         SortNet<CHB>::sort(b);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
-        constexpr int G = 8;  // see spearman_split_kernel
+        constexpr int G = 4;  // see spearman_split_kernel
 #pragma unroll
         for (int p0 = 0; p0 < CHB; p0 += G) {
-            const bool guarded = !EXACT && p0 >= SURE_B;
-            uint32_t key[G], less[G];
-            uint32_t batch_tie = 0xFFFFFFFFu;
+            const bool guarded = !EXACT && p0 >= SURE_B;  // compile time per batch
+            if (!guarded || p0 + G <= nB) {
+                uint32_t key[G], less[G];
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                const int p = p0 + g;
-                const bool real = !guarded || p < nB;
-                key[g] = composite_key(b[p]);
-                if (p > 0) tie_min = min(tie_min, real ? key[g] ^ prev : 0xFFFFFFFFu);
-                if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
-                if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
-                prev = key[g];
+                for (int g = 0; g < G; g++) {
+                    const int p = p0 + g;
+                    key[g] = composite_key(b[p]);
+                    if (p > 0) tie_min = min(tie_min, key[g] ^ prev);
+                    if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
+                    if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
+                    prev = key[g];
+                }
+                lower_bound_col_batch<CH, G>(&keysA[lane], key, tie_min, less);
+                // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
+#pragma unroll
+                for (int g = 0; g < G; g++) discordant += CH - int32_t(less[g]);
+            } else {
+#pragma unroll
+                for (int p = p0; p < p0 + G; p++) {
+                    if (p < nB) {
+                        const uint32_t key = composite_key(b[p]);
+                        if (p > 0) tie_min = min(tie_min, key ^ prev);
+                        if (p == 0) is_nan |= key < 0x007FFFFFu;
+                        if (p == nB - 1) is_nan |= key > 0xFF800000u;
+                        prev = key;
+                        discordant += CH - int32_t(lower_bound_col<CH>(&keysA[lane], key, tie_min));
+                    }
+                }
             }
-            lower_bound_col_batch<CH, G>(&keysA[lane], key, guarded ? batch_tie : tie_min, less);
-            if (guarded) tie_min = min(tie_min, batch_tie);
-            // every a in A has a smaller x than b: the pair is discordant iff y_a > y_b
-#pragma unroll
-            for (int g = 0; g < G; g++) discordant += (!guarded || p0 + g < nB) ? CH - int32_t(less[g]) : 0;
         }
         discordant += chunk_inversions<CHB, SURE_B>(b, nB, EXACT);
     }
