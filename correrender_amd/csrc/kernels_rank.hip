@@ -170,19 +170,24 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
             is_nan |= composite_key(a[p]) > ((p == cs - 1) ? 0xFF800000u : 0xFFFFFFFFu);
     }
 
-    // Tie-free fast path (exact instantiations): when no lane of the wave has two equal values -- the rule for
+    // Tie-free fast path: when no lane of the wave has two equal values among its members -- the rule for
     // continuous data; tied voxels cluster in space, so whole waves are free of them -- rank = position + 1 and the two
     // tie-run scans (~8 vector instructions per element) are skipped.  Same values as the scans would produce.
     bool scanned = true;
-    if constexpr (EXACT) {
+    {
+        // (guarded instantiations: the pads tie with each other and are left out of the test; their rank slots are
+        // masked when the ranks are read back)
         uint32_t tie_min = 0xFFFFFFFFu;  // min over neighbours of (key ^ previous key): 0 iff the voxel has a tie
 #pragma unroll
-        for (int p = 1; p < N; p++) tie_min = min(tie_min, composite_key(a[p]) ^ composite_key(a[p - 1]));
+        for (int p = 1; p < N; p++) {
+            const uint32_t x = composite_key(a[p]) ^ composite_key(a[p - 1]);
+            tie_min = min(tie_min, (EXACT || p < SURE || p < cs) ? x : 0xFFFFFFFFu);
+        }
         if (!__any(tie_min == 0u)) {
             scanned = false;
 #pragma unroll
             for (int p = 0; p < N; p++)
-                rank2[(composite_low(a[p]) & 0xFFu) * 64 + lane] = uint16_t(2 * p + 2);
+                if (EXACT || p < SURE || p < cs) rank2[(composite_low(a[p]) & 0xFFu) * 64 + lane] = uint16_t(2 * p + 2);
         }
     }
     if (scanned) {
