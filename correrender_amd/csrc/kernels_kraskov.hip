@@ -886,24 +886,67 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     // up to 80 members the x distances come from the prepared table (scalar loads)
     const char* dxt_env = getenv("CRF_KRASKOV_DXT");  // tuning: 0 = compute them per pair
     const bool use_dxt = cs <= kDxtMaxMembers && !(dxt_env && *dxt_env == '0');
-#define CRF_LAUNCH_DIRECT_DXT(K)                                                                                       \
-    hipLaunchKernelGGL((kraskov_direct_kernel<K, 8, false, true>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, \
+#define CRF_LAUNCH_DIRECT_DXT_TI(K, TI)                                                                                  \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, false, true>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, \
                        prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
+#define CRF_LAUNCH_DIRECT_DXT(K) CRF_LAUNCH_DIRECT_DXT_TI(K, 8)
+    // 4 points per sweep instead of 8 for K = 3 and 4: half the registers (94 / 119 instead of 156 / 188: 5 / 4 waves per
+    // SIMD instead of 3 / 2) and one s_load_dwordx8 per candidate row -- 256^3 with the table: k = 4 at 32 / 48 / 64 / 80
+    // members 8.7 / 17.5 / 30.5 / 46.4 ms against 10.6 / 21.6 / 37.9 / 57.7 ms, k = 3 at 48 / 64 / 80: 14.8 / 25.8 / 39.3
+    // against 15.4 / 27.0 / 41.7 ms; K = 1, 2 lose (64 members: 20.6 / 23.0 vs 18.0 / 21.1 ms).  Without the table
+    // (beyond 80 members) K = 4 gains (128 members 129 vs 149 ms), K = 3 loses (117 vs 108 ms).
+    const char* ti4_env = getenv("CRF_KRASKOV_TI4");  // tuning: 1 = 4 points per sweep for every K <= 4, 0 = 8
+    const bool ti4_table = ti4_env ? *ti4_env == '1' : kk >= 3;
+    const bool ti4_k4 = ti4_env ? *ti4_env == '1' : true;
+    const bool ti4_k3_plain = ti4_env && *ti4_env == '1';
+    const bool ti4 = ti4_table;
     if (use_dxt && kk <= 4) {
         switch (kk) {
-            case 1: CRF_LAUNCH_DIRECT_DXT(1); break;
-            case 2: CRF_LAUNCH_DIRECT_DXT(2); break;
-            case 3: CRF_LAUNCH_DIRECT_DXT(3); break;
-            default: CRF_LAUNCH_DIRECT_DXT(4); break;
+            case 1:
+                if (ti4) {
+                    CRF_LAUNCH_DIRECT_DXT_TI(1, 4);
+                } else {
+                    CRF_LAUNCH_DIRECT_DXT(1);
+                }
+                break;
+            case 2:
+                if (ti4) {
+                    CRF_LAUNCH_DIRECT_DXT_TI(2, 4);
+                } else {
+                    CRF_LAUNCH_DIRECT_DXT(2);
+                }
+                break;
+            case 3:
+                if (ti4) {
+                    CRF_LAUNCH_DIRECT_DXT_TI(3, 4);
+                } else {
+                    CRF_LAUNCH_DIRECT_DXT(3);
+                }
+                break;
+            default:
+                if (ti4) {
+                    CRF_LAUNCH_DIRECT_DXT_TI(4, 4);
+                } else {
+                    CRF_LAUNCH_DIRECT_DXT(4);
+                }
+                break;
         }
     } else if (kk == 1) {
         CRF_LAUNCH_DIRECT(1, 8);
     } else if (kk == 2) {
         CRF_LAUNCH_DIRECT(2, 8);
     } else if (kk == 3) {
-        CRF_LAUNCH_DIRECT(3, 8);
+        if (ti4_k3_plain) {
+            CRF_LAUNCH_DIRECT(3, 4);
+        } else {
+            CRF_LAUNCH_DIRECT(3, 8);
+        }
     } else if (kk <= 4) {
-        CRF_LAUNCH_DIRECT(4, 8);
+        if (ti4_k4) {
+            CRF_LAUNCH_DIRECT(4, 4);
+        } else {
+            CRF_LAUNCH_DIRECT(4, 8);
+        }
     } else if (kk <= 8) {
         CRF_LAUNCH_DIRECT(8, 4);
     } else if (kk <= 16) {
@@ -917,6 +960,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     }
 #undef CRF_LAUNCH_DIRECT
 #undef CRF_LAUNCH_DIRECT_DXT
+#undef CRF_LAUNCH_DIRECT_DXT_TI
     if (ev_end) (void)hipEventRecord(ev_end, s);
     if (info) info->kernel_name = "kraskov_direct_kernel";
     return hipGetLastError();
@@ -1017,21 +1061,22 @@ hipError_t launch_mi_kraskov(const float* const* d_members, int cs, size_t num_v
     // The LDS-tile kernels below are instantiated for k <= 4 and hold a 256*cs-byte column per wave, which caps the
     // occupancy beyond ~80 members (measured at 256^3, k = 3: 80 members 71 vs 72 ms, 96: 112 vs 100 ms, 128: 226 vs
     // 171 ms, tile vs tile-free): the tile-free kernel takes over there and for every larger k.
-    // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Up to 44 members the
-    // LDS-column kernel with 8 points per sweep wins (three to four waves per SIMD: k = 3 at 32 / 40 / 44 members 7.2 /
-    // 11.6 / 14.7 ms vs 7.8 / 12.8 / 15.2 ms tile-free), for k = 4 up to 56 members (31.6 vs 32.7 ms).  Beyond that the
-    // tile-free kernel with the scalar-loaded x-distance table (k = 3: 48 / 56 / 64 / 80 members 15.3 / 23.0 / 26.8 / 41.8
-    // ms; LDS column 16.4 / 23.9 / - / -) -- its four waves share a voxel tile, so its re-reads stay in L1 / L2 (see the
-    // kernel).  k = 4 at 57..64 members goes to the sorted-column kernel (34.9 vs 37.8 ms).
+    // r02 dispatch (256^3, profiles/r02_kraskov_tile_vs_direct.txt, profiles/tuning_r02.md).  Small member counts: the
+    // LDS-column kernel with 8 points per sweep (three to four waves per SIMD, no batch padding): k = 3 at 32 / 40
+    // members 7.2 / 11.5 ms vs 7.2 / 12.4 ms tile-free.  Beyond that the tile-free kernel with the scalar-loaded
+    // x-distance table, 8 points per sweep for k = 1, 2 and 4 for k = 3, 4 (k = 3: 48 / 56 / 64 / 80 members 14.8 / 22.2 /
+    // 25.8 / 39.3 ms; k = 4: 32 / 48 / 64 / 80 members 8.5 / 17.5 / 30.5 / 46.4 ms, LDS column 9.5 / 21.7 / - / -) -- its
+    // four waves share a voxel tile, so its re-reads stay in L1 / L2 (see the kernel).  The sorted-column kernel (k = 4
+    // at 64 members: 34.9 ms) is no longer the fastest anywhere and runs only when asked for (CRF_KRASKOV_SORTED=1).
     const char* sorted = getenv("CRF_KRASKOV_SORTED");  // tuning: 1 = wherever it exists, 0 = never
     if (kk <= 4 && cs <= 64 && !(sorted && *sorted == '0') && !(force_direct && *force_direct == '1') &&
-        ((sorted && *sorted == '1') || (cs > 56 && kk == 4))) {
+        (sorted && *sorted == '1')) {
         hipError_t e = launch_mi_kraskov_sorted(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,
                                                 ev_end, info);
         if (e != hipErrorNotSupported) return e;
     }
     const char* force_tile = getenv("CRF_KRASKOV_TILE");  // tuning: the LDS-column kernel wherever it exists
-    const bool prefer_direct = cs > 56 || (cs > 44 && kk <= 3);
+    const bool prefer_direct = kk <= 2 ? cs > 44 : (kk == 3 ? cs > 40 : (cs > 36 || (cs > 28 && cs <= 32)));
     if (kk > 4 || cs > 80 || (force_direct && *force_direct == '1') ||
         (prefer_direct && !(force_tile && *force_tile == '1'))) {
         hipError_t e = launch_mi_kraskov_direct(d_members, cs, num_voxels, ref, a, d_tables, d_prep, d_out, s, ev_begin,

@@ -137,14 +137,15 @@ def test_binned_positive_overflow_of_the_bin_index(engine, oracle, cs):
 
 
 @pytest.mark.parametrize("variant", ["CRF_KRASKOV_SORTED", "CRF_KRASKOV_DIRECT", "CRF_KRASKOV_TILE"])
-@pytest.mark.parametrize("dxt", ["0", "1"])
+@pytest.mark.parametrize("dxt,ti4", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
 @pytest.mark.parametrize("cs", [9, 20, 32, 33, 47, 48, 57, 63, 64])
-def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, cs):
+def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, ti4, cs):
     """The three Kraskov kernels (sorted-column, tile-free, LDS-column) forced one at a time -- the dispatch picks one per
     (cs, k), so without this a kernel is only exercised where it is the default; the launchers read the variable at
     every call.  Includes a box ensemble (exact ties, resolved by the noise), a NaN voxel and both estimators."""
     monkeypatch.setenv(variant, "1")
     monkeypatch.setenv("CRF_KRASKOV_DXT", dxt)     # x distances from the prepared table (scalar loads) or per pair
+    monkeypatch.setenv("CRF_KRASKOV_TI4", ti4)     # tile-free kernel: 4 or 8 points per sweep
     for k in (1, 2, 3, 4):
         for estimator in (1, 2):
             ens = synth.normal_ensemble(16, 6, 5, cs, seed=70 * cs + k)
