@@ -894,7 +894,8 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     // SIMD instead of 3 / 2) and one s_load_dwordx8 per candidate row -- 256^3 with the table: k = 4 at 32 / 48 / 64 / 80
     // members 8.7 / 17.5 / 30.5 / 46.4 ms against 10.6 / 21.6 / 37.9 / 57.7 ms, k = 3 at 48 / 64 / 80: 14.8 / 25.8 / 39.3
     // against 15.4 / 27.0 / 41.7 ms; K = 1, 2 lose (64 members: 20.6 / 23.0 vs 18.0 / 21.1 ms).  Without the table
-    // (beyond 80 members) K = 4 gains (128 members 129 vs 149 ms), K = 3 loses (117 vs 108 ms).
+    // (beyond 80 members) K = 4 gains (128 members 129 vs 149 ms), K = 3 loses (117 vs 108 ms).  2 points per sweep
+    // (77-79 registers, 6 waves) lose again: 64 members k = 3 / 4 31.5 / 34.8 ms.
     const char* ti4_env = getenv("CRF_KRASKOV_TI4");  // tuning: 1 = 4 points per sweep for every K <= 4, 0 = 8
     const bool ti4_table = ti4_env ? *ti4_env == '1' : kk >= 3;
     const bool ti4_k4 = ti4_env ? *ti4_env == '1' : true;
