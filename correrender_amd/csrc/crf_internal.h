@@ -13,7 +13,7 @@ constexpr int kMaxRegisterMembers = 384;  // 257..384: VGPRs + AGPRs + a little 
 // Largest member count supported at all by the sort-based estimators (LDS / register budgets).
 constexpr int kMaxSortMembers = 128;
 // Prepared reference-derived table: floats (see each kernels_*.hip for its layout).
-constexpr size_t kPrepBytes = 64 * 1024;
+constexpr size_t kPrepBytes = 160 * 1024;  // (r02: room for the Kraskov x-distance table of 128 members, 133 KB)
 // Largest member count of the generic (any-cs) kernels: bounded by the preparation scratch (2*cs ints / doubles).
 constexpr int kMaxGenericMembers = 2048;
 // where binned_prep_kernel leaves the reference-side entropy sum (fp64) inside the preparation scratch

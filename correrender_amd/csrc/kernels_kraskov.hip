@@ -37,10 +37,10 @@ namespace crf {
 // prep (fp64 view): [0, cs) px_e = double(ref_e) + noise_ref_e (MutualInformation.cpp:417-420), member order;
 //                   [cs, 2cs) the same values sorted ascending (the reference sorts them for its 1-D range counts,
 //                   MutualInformation.cpp:187; voxel independent, so sorted once per evaluation)
-// the distance table fits the 64 KB preparation buffer behind the two coordinate vectors up to 80 members
-constexpr int kDxtMaxMembers = 80;
+// the distance table lies in the preparation buffer behind the two coordinate vectors (up to 128 members: 133 KB)
+constexpr int kDxtMaxMembers = 128;
 __host__ __device__ inline int dxt_offset(int cs) { return (2 * cs + 7) / 8 * 8; }  // in doubles
-static_assert(size_t(((2 * kDxtMaxMembers + 7) / 8 * 8) + 80 * 80) * sizeof(double) <= kPrepBytes - 16, "prep buffer");
+static_assert(size_t(((2 * kDxtMaxMembers + 7) / 8 * 8) + 128 * 128) * sizeof(double) <= kPrepBytes - 16, "prep buffer");
 
 __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                            int cs, const double* __restrict__ noise_ref,
@@ -883,9 +883,13 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
                        noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
     // K = k exactly for the small k (the sorted insertion costs 2K - 1 min/max per candidate: K = 4 for k = 3 is 7
     // instead of 5; measured at 256^3 x 64, k = 3: <3, 8> 36.2 ms vs <4, 8> 48.6 ms)
-    // up to 80 members the x distances come from the prepared table (scalar loads)
+    // up to 128 members the x distances can come from the prepared table (scalar loads)
     const char* dxt_env = getenv("CRF_KRASKOV_DXT");  // tuning: 0 = compute them per pair
-    const bool use_dxt = cs <= kDxtMaxMembers && !(dxt_env && *dxt_env == '0');
+    // (the table outgrows the 16 KB scalar cache early but keeps paying up to 112 members -- 256^3: 100 members k = 3 / 4
+    // 67.8 / 79.5 vs 76.2 / 87.7 ms -- and for k = 2, 4 up to 128: 81.6 / 122.5 vs 85.6 / 129.9 ms; k = 1, 3 at 128: 74.5 /
+    // 109.9 vs 73.3 / 107.6 ms)
+    const bool table_pays = cs <= 112 || kk == 2 || kk == 4;
+    const bool use_dxt = cs <= kDxtMaxMembers && ((dxt_env && *dxt_env == '1') || (table_pays && !(dxt_env && *dxt_env == '0')));
 #define CRF_LAUNCH_DIRECT_DXT_TI(K, TI)                                                                                  \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, false, true>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, \
                        prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)

@@ -161,11 +161,15 @@ def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, ti4,
     assert engine.last_kernel_name() == expected
 
 
-@pytest.mark.parametrize("cs", [65, 72, 79, 80, 81, 88])
-def test_kraskov_distance_table_boundary(engine, oracle, cs):
-    """The x-distance table exists up to 80 members (it shares the 64 KB preparation buffer): both sides of the limit,
-    member counts that are not multiples of the 8-point sweep or the 16-candidate batch."""
-    for k in (1, 3, 4):
+@pytest.mark.parametrize("dxt", [None, "0", "1"])
+@pytest.mark.parametrize("cs", [65, 72, 79, 80, 81, 88, 111, 112, 113, 127, 128, 129, 140])
+def test_kraskov_distance_table_boundary(engine, oracle, monkeypatch, cs, dxt):
+    """The x-distance table exists up to 128 members (it lies in the preparation buffer) and is used up to 112 members
+    for every k, up to 128 for k = 2, 4: both sides of the limits, with the default choice and with the table forced
+    off / on, member counts that are not multiples of the sweep width or the 16-candidate batch."""
+    if dxt is not None:
+        monkeypatch.setenv("CRF_KRASKOV_DXT", dxt)
+    for k in (1, 2, 3, 4):
         ens = synth.normal_ensemble(16, 6, 4, cs, seed=5 * cs + k)
         _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
                f"KSG-1 cs={cs} k={k}", ref_xyz=(7, 3, 2), k=k, min_identical=0.99)
