@@ -56,6 +56,7 @@ SYMBOLS = {
     "crf_upload_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_bind_members_device": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crf_member_minmax_divergent": (C.c_int, [_VOIDP, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_upload_secondary_members": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_bind_secondary_members_device": (C.c_int, [_VOIDP, C.POINTER(_VOIDP)]),
     "crf_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -98,6 +99,8 @@ SYMBOLS = {
     "crf_group_secondary_member_minmax": (C.c_int, [_VOIDP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crf_group_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
     "crf_group_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(_VOIDP)]),
+    "crf_group_compute_batch": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.c_int, C.POINTER(_VOIDP)]),
+    "crf_group_compute_batch_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.c_int, C.POINTER(_VOIDP)]),
     "crf_group_set_profiling": (C.c_int, [_VOIDP, C.c_int]),
     "crf_group_take_kernel_time": (C.c_int, [_VOIDP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -13,7 +13,13 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <immintrin.h>
+#include <sys/mman.h>
+
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <limits>
 #include <memory>
 #include <string>
@@ -160,7 +166,7 @@ hipEvent_t take_event(crf_context* c) {
 
 extern "C" {
 
-int crf_abi_version(void) { return 4; }
+int crf_abi_version(void) { return 5; }
 
 const char* crf_last_error(const crf_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -224,7 +230,10 @@ void crf_destroy(crf_context* c) {
     if (c->d_request_out) (void)hipFree(c->d_request_out);
     if (c->d_minmax) (void)hipFree(c->d_minmax);
     if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
+    c->copy_pool.reset();
     if (c->h_staging) (void)hipHostFree(c->h_staging);
+    if (c->prep_done) (void)hipEventDestroy(c->prep_done);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (hipEvent_t e : c->chunk_done)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->chunk_copied)
@@ -263,6 +272,7 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
     if (c->h_staging) (void)hipHostFree(c->h_staging);
     c->h_staging = nullptr;
+    c->d_staging = nullptr;
     c->d_chunk_tables = nullptr;
     c->host_chunks = 0;
     c->d_todo = nullptr;
@@ -359,6 +369,15 @@ int crf_member_minmax(crf_context* c, float* out_min, float* out_max) {
     }
     *out_min = c->min_v;
     *out_max = c->max_v;
+    return CRF_OK;
+}
+
+int crf_member_minmax_divergent(crf_context* c, int secondary, float* out_min, float* out_max) {
+    float mn = 0.f, mx = 0.f;
+    if (int r = secondary ? crf_secondary_member_minmax(c, &mn, &mx) : crf_member_minmax(c, &mn, &mx)) return r;
+    const float max_abs = std::max(std::abs(mn), std::abs(mx));  // VolumeData.cpp:1662-1666
+    *out_min = -max_abs;
+    *out_max = max_abs;
     return CRF_OK;
 }
 
@@ -540,115 +559,89 @@ int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
     return CRF_OK;
 }
 
-// Device result -> the caller's (pageable) host buffer.  The caller of calculateCpu owns a freshly allocated
-// `new float[xs*ys*zs]` (VolumeData.cpp:1222-1226): pageable and never touched.  Measured at 256^3 (67 MB): hipMemcpy into
-// such a buffer takes ~6.3 ms, into an already touched one 1.2 ms (58 GB/s) -- the difference is first-touch page
-// faults taken one at a time inside the copy.  So the pages are faulted in first, by a few host threads in parallel and
-// while the kernel that produces the result is still running, and the copy itself is the runtime's plain one.  (A
-// hand-rolled pipeline through a pinned staging buffer was measured slower than the runtime's copy: 2.45 vs 1.86 ms
-// into a touched buffer.)  Writing zeros ahead of the result is harmless: the buffer's content is ours to define.
+// ---- device result -> the caller's (pageable) host buffer -------------------------------------------------------------
+// The caller of calculateCpu owns a freshly allocated `new float[xs*ys*zs]` (VolumeData.cpp:1222-1226): pageable and never
+// touched.  Measured on MI355X hosts at 256^3 (67 MB, profiles/r03_host_boundary.md): one DMA into pinned memory 1.19 ms
+// (56.5 GB/s, the PCIe floor); a kernel storing straight into device-mapped pinned memory 1.22 ms; 8 host threads move
+// pinned -> resident pageable memory at 120 GB/s but only at 14 GB/s into never-touched pages (first-touch faults).
 //
-// PageToucher faults the destination in, range by range in the order the ranges will be copied; wait(j) returns once
-// range j is resident.
-class PageToucher {
-public:
-    PageToucher(float* host_out, size_t count, size_t range_count, int ranges) {
-        const char* plain = getenv("CRF_PLAIN_D2H");
-        const size_t bytes = count * sizeof(float);
-        if (bytes < (size_t(8) << 20) || (plain && *plain == '1')) return;
-        constexpr size_t kPage = 4096;
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t workers = std::min<size_t>(16, hw > 1 ? hw / 2 : 1);
-        ranges_ = ranges;
-        done_ = std::make_unique<std::atomic<int>[]>(size_t(ranges));
-        for (int j = 0; j < ranges; j++) done_[size_t(j)].store(0, std::memory_order_relaxed);
-        workers_ = int(workers);
-        char* base = reinterpret_cast<char*>(host_out);
-        pool_.reserve(workers);
-        for (size_t w = 0; w < workers; w++) {
-            pool_.emplace_back([=]() {
-                for (int j = 0; j < ranges; j++) {
-                    const size_t r_lo = size_t(j) * range_count * sizeof(float);
-                    const size_t r_hi = std::min(bytes, r_lo + range_count * sizeof(float));
-                    const size_t per = ((r_hi - r_lo) / workers + kPage) & ~(kPage - 1);
-                    const size_t lo = r_lo + w * per, hi = std::min(r_hi, lo + per);
-                    if (lo < hi) {
-                        for (size_t off = lo; off < hi; off += kPage) static_cast<volatile char*>(base)[off] = 0;
-                        static_cast<volatile char*>(base)[hi - 1] = 0;
-                    }
-                    done_[size_t(j)].fetch_add(1, std::memory_order_release);
-                }
+// So a host-output evaluation is a pipeline over a few voxel RANGES (ensure_host_ranges):
+//   GPU     the per-voxel kernel of each range stores its results straight into a pinned, device-mapped staging buffer
+//           (no device-side result buffer, no DMA engine: the stores cross PCIe while the kernel runs -- the kernel is
+//           simply throttled to the link rate, which is the floor anyway);
+//   host    a persistent pool of copier threads (crf_pool.h) moves each finished range from the staging buffer into
+//           the caller's buffer, and while it waits for a range it faults the destination pages of the ranges ahead in
+//           (MADV_POPULATE_WRITE batches the faults; transparent huge pages are requested for the buffer first).
+// Ranges shrink towards the end so that the last copy -- the only one not hidden behind a kernel -- is small.
+// CRF_HOST_PATH=dma keeps results in HBM and copies each range with the DMA engine instead (also used when a post-pass
+// has to read the result back: CRF_FLAG_ABSOLUTE_VALUE).
+constexpr int kMadvPopulateWrite = 23;  // MADV_POPULATE_WRITE (Linux 5.14), not in every libc header
+constexpr size_t kPage = 4096;
+
+static int env_int_or(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+
+// faults [lo, hi) of the caller's buffer in (write access); mode 0: leave it to the copy, 1: touch, 2: populate
+static void fault_in(char* base, size_t lo, size_t hi, int mode) {
+    if (mode == 0 || lo >= hi) return;
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(base) + lo) & ~(kPage - 1);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(base) + hi + kPage - 1) & ~(kPage - 1);
+    if (mode == 2 && madvise(reinterpret_cast<void*>(a), e - a, kMadvPopulateWrite) == 0) return;
+    // fallback / mode 1: one write per page.  The bytes written are inside the caller's buffer and are overwritten by
+    // the result afterwards.
+    for (size_t off = lo; off < hi; off += kPage) static_cast<volatile char*>(base)[off] = 0;
+    static_cast<volatile char*>(base)[hi - 1] = 0;
+}
+
+// thread w's share of byte range [r_lo, r_hi) among `workers` threads, split on page boundaries
+static void thread_share(size_t r_lo, size_t r_hi, int w, int workers, size_t* lo, size_t* hi) {
+    const size_t per = (((r_hi - r_lo) + size_t(workers) - 1) / size_t(workers) + kPage - 1) & ~(kPage - 1);
+    *lo = std::min(r_hi, r_lo + size_t(w) * per);
+    *hi = std::min(r_hi, *lo + per);
+}
+
+static int ensure_copy_pool(crf_context* c) {
+    if (c->copy_pool) return CRF_OK;
+    const unsigned hw = std::thread::hardware_concurrency();
+    int cap = int(std::min<unsigned>(16u, std::max(1u, hw / 2)));
+    if (c->copy_threads_cap > 0) cap = std::min(cap, c->copy_threads_cap);
+    const int forced = env_int_or("CRF_COPY_THREADS", 0);
+    if (forced >= 1) cap = std::min(forced, 64);
+    // copier threads idle-spin for a short while only: back-to-back evaluations hand over within ~0.1 ms
+    c->copy_pool = std::make_unique<crf::SpinPool>(cap, nullptr, 300e-6);
+    c->copy_threads = cap;
+    if (forced >= 1 || cap <= 2) return CRF_OK;
+    // one-off calibration: how many of the pool's threads move pinned -> pageable memory fastest on this host
+    const size_t bytes = std::min<size_t>(c->alloc_voxels * sizeof(float), size_t(16) << 20);
+    std::vector<char> dst(bytes, 1);
+    const char* src = reinterpret_cast<const char*>(c->h_staging);
+    double best = 1e30;
+    for (int t : {2, 4, 8, 12, 16}) {
+        if (t > cap) break;
+        double fastest = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            c->copy_pool->run([&](int w) -> int {
+                if (w >= t) return 0;
+                size_t lo, hi;
+                thread_share(0, bytes, w, t, &lo, &hi);
+                if (lo < hi) memcpy(dst.data() + lo, src + lo, hi - lo);
+                return 0;
             });
+            fastest = std::min(fastest, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (fastest < best * 0.93) {  // more threads only for a real gain
+            best = fastest;
+            c->copy_threads = t;
         }
     }
-    void wait(int j) const {
-        if (!done_) return;
-        while (done_[size_t(j)].load(std::memory_order_acquire) < workers_) std::this_thread::yield();
-    }
-    ~PageToucher() {
-        for (auto& t : pool_) t.join();
-    }
+    return CRF_OK;
+}
 
-private:
-    std::unique_ptr<std::atomic<int>[]> done_;
-    std::vector<std::thread> pool_;
-    int ranges_ = 0, workers_ = 0;
-};
-
-// Moves landed ranges from the pinned staging buffer into the caller's (pageable, possibly never-touched) buffer with a
-// few host threads; a range is copied once release(j) has been called for it.
-class StagedCopier {
-public:
-    StagedCopier(const float* staging, float* host_out, size_t count, size_t range_count, int ranges)
-        : ready_(std::make_unique<std::atomic<int>[]>(size_t(ranges))) {
-        for (int j = 0; j < ranges; j++) ready_[size_t(j)].store(0, std::memory_order_relaxed);
-        const unsigned hw = std::thread::hardware_concurrency();
-        size_t workers = std::min<size_t>(8, hw > 1 ? hw / 2 : 1);
-        if (const char* w = getenv("CRF_COPY_THREADS"); w && atoi(w) >= 1) workers = size_t(atoi(w));
-        const size_t bytes = count * sizeof(float);
-        const char* src = reinterpret_cast<const char*>(staging);
-        char* dst = reinterpret_cast<char*>(host_out);
-        std::atomic<int>* ready = ready_.get();
-        pool_.reserve(workers);
-        for (size_t w = 0; w < workers; w++) {
-            pool_.emplace_back([=]() {
-                constexpr size_t kPage = 4096;
-                for (int j = 0; j < ranges; j++) {
-                    const size_t r_lo = size_t(j) * range_count * sizeof(float);
-                    const size_t r_hi = std::min(bytes, r_lo + range_count * sizeof(float));
-                    const size_t per = ((r_hi - r_lo) / workers + kPage) & ~(kPage - 1);
-                    const size_t lo = r_lo + w * per, hi = std::min(r_hi, lo + per);
-                    while (ready[size_t(j)].load(std::memory_order_acquire) == 0) std::this_thread::yield();
-                    if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
-                }
-            });
-        }
-    }
-    void release(int j) { ready_[size_t(j)].store(1, std::memory_order_release); }
-    void finish() {
-        for (auto& t : pool_) t.join();
-        pool_.clear();
-    }
-    ~StagedCopier() {  // an error path: let the threads run out (they copy whatever the staging buffer holds)
-        if (!pool_.empty()) {
-            // ranges are released in order, so releasing all is enough to end every wait
-            for (size_t j = 0; ready_ && j < n_release_; j++) ready_[j].store(1, std::memory_order_release);
-            finish();
-        }
-    }
-    void set_release_count(size_t n) { n_release_ = n; }
-
-private:
-    std::unique_ptr<std::atomic<int>[]> ready_;
-    std::vector<std::thread> pool_;
-    size_t n_release_ = 0;
-};
-
+// Plain form for small results and the sibling reductions: kernel into HBM, one copy.
 static int copy_result_to_host(crf_context* c, const float* d_src, float* host_out, size_t count) {
-    {
-        PageToucher toucher(host_out, count, count, 1);
-        toucher.wait(0);
-    }
     CRF_HIP(c, hipMemcpyAsync(host_out, d_src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     return CRF_OK;
@@ -657,7 +650,7 @@ static int copy_result_to_host(crf_context* c, const float* d_src, float* host_o
 // phase: bit 0 = reference-side preparation, bit 1 = per-voxel kernel (crf_internal.h RefSource::phase);
 // slot < 0: the context's own preparation buffer
 static int compute_impl(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
-                        void* stream, unsigned phase, int slot) {
+                        void* stream, unsigned phase, int slot, const crf::RefOverride* ov = nullptr) {
     if (int r = check_ready(c)) return r;
     if (!p || (!device_out && (phase & 2u))) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (p->measure < CRF_PEARSON || p->measure > CRF_KMI_CC)
@@ -684,6 +677,10 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
     ref.phase = phase;
     if (!(phase & 1u)) {
         ref.values = nullptr;  // prepared earlier: no reference vector is read
+    } else if (!ref.values && ov) {
+        // crf_group, direct exchange: the preparation kernel reads the values out of another context's members
+        ref.table = ov->table;
+        ref.voxel = ov->voxel;
     } else if (!ref.values && (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY)) {
         if (c->sec_members.empty())
             return fail(c, CRF_ERR_STATE, "CRF_FLAG_REFERENCE_FROM_SECONDARY needs secondary members");
@@ -692,7 +689,7 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
         CRF_HIP(c, crf::launch_gather_reference(c->d_sec_table, c->cs, voxel, c->d_ref, s));
         ref.values = c->d_ref;
     }
-    if ((phase & 1u) && !ref.values) {
+    if ((phase & 1u) && !ref.values && !ref.table) {
         if (p->reference_values) {
             CRF_HIP(c, hipMemcpyAsync(c->d_ref, p->reference_values, sizeof(float) * size_t(c->cs),
                                       hipMemcpyHostToDevice, s));
@@ -840,42 +837,53 @@ int crf_prepare_device(crf_context* c, const crf_params* p, const void* device_r
 }
 
 int crf_compute(crf_context* c, const crf_params* p, float* host_out) {
-    return crf::compute_to_host(c, p, nullptr, host_out);
+    return crf::compute_to_host(c, p, nullptr, host_out, nullptr);
 }
 
 }  // extern "C"
 
 namespace {
 // The voxel ranges of a host-output evaluation: one member-pointer table per range (pointers advanced by the range's
-// first voxel), so that every per-voxel kernel can be launched on a range without knowing about ranges.
-int ensure_host_chunks(crf_context* c) {
+// first voxel), so that every per-voxel kernel can be launched on a range without knowing about ranges.  Range lengths
+// are multiples of 1024 voxels (4 KiB: every range stays as aligned as the members themselves) and shrink towards the
+// end: the copy of the last range into the caller's buffer is the only host work no kernel hides.
+int ensure_host_ranges(crf_context* c) {
     if (c->host_chunks > 0) return CRF_OK;
     const size_t n = c->alloc_voxels;
-    int chunks = 1;
-    const char* forced = getenv("CRF_HOST_CHUNKS");
-    if (forced && atoi(forced) >= 1) {
-        chunks = std::min(atoi(forced), kMaxHostChunks);
-    } else if (n * sizeof(float) >= (size_t(8) << 20)) {
-        chunks = 8;  // measured at 256^3 (67 MB): 8 ranges 1.60 ms, 16 ranges 1.73 ms, 1 range 1.86 ms; pure DMA 1.35 ms
+    std::vector<size_t> first{0};
+    const int forced = env_int_or("CRF_HOST_CHUNKS", 0);
+    if (forced >= 1) {  // experiments: equal ranges
+        size_t per = (n + size_t(forced) - 1) / size_t(forced);
+        per = (per + 1023) & ~size_t(1023);
+        for (size_t at = per; at < n && int(first.size()) < kMaxHostChunks; at += per) first.push_back(at);
+    } else {
+        // shares of 64: 16 14 11 8 6 4 3 2 -- each range at least ~2/3 of the one before it (the copier threads move a
+        // range about twice as fast as the link delivers the next one), the last one 1/32 of the result
+        static const int kShares[] = {16, 14, 11, 8, 6, 4, 3, 2};
+        size_t acc = 0;
+        for (int j = 0; j + 1 < int(sizeof kShares / sizeof *kShares); j++) {
+            acc += size_t(kShares[j]);
+            const size_t at = (n / 64 * acc + 1023) & ~size_t(1023);
+            if (at > first.back() && at < n) first.push_back(at);
+        }
     }
-    // range length: a multiple of 1024 voxels (4 KiB: keeps every range as aligned as the members themselves)
-    size_t per = (n + size_t(chunks) - 1) / size_t(chunks);
-    per = (per + 1023) & ~size_t(1023);
-    chunks = int((n + per - 1) / per);
-    std::vector<const float*> table(size_t(chunks) * size_t(c->cs));
-    for (int j = 0; j < chunks; j++)
-        for (int m = 0; m < c->cs; m++) table[size_t(j) * size_t(c->cs) + size_t(m)] = c->members[size_t(m)] + size_t(j) * per;
+    const int ranges = int(first.size());
+    first.push_back(n);
+    std::vector<const float*> table(size_t(ranges) * size_t(c->cs));
+    for (int j = 0; j < ranges; j++)
+        for (int m = 0; m < c->cs; m++) table[size_t(j) * size_t(c->cs) + size_t(m)] = c->members[size_t(m)] + first[size_t(j)];
     if (c->d_chunk_tables) (void)hipFree(c->d_chunk_tables);
     c->d_chunk_tables = nullptr;
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_chunk_tables), table.size() * sizeof(float*)));
     CRF_HIP(c, hipMemcpy(c->d_chunk_tables, table.data(), table.size() * sizeof(float*), hipMemcpyHostToDevice));
     if (!c->copy_stream) CRF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (int j = 0; j < chunks; j++)
+    for (int j = 0; j < ranges; j++)
         if (!c->chunk_done[j]) CRF_HIP(c, hipEventCreateWithFlags(&c->chunk_done[j], hipEventDisableTiming));
-    for (int j = 0; j < chunks; j++)
+    for (int j = 0; j < ranges; j++)
         if (!c->chunk_copied[j]) CRF_HIP(c, hipEventCreateWithFlags(&c->chunk_copied[j], hipEventDisableTiming));
-    c->chunk_voxels = per;
-    c->host_chunks = chunks;
+    if (!c->prep_done) CRF_HIP(c, hipEventCreateWithFlags(&c->prep_done, hipEventDisableTiming));
+    for (int j = 0; j <= ranges; j++) c->chunk_first[j] = first[size_t(j)];
+    c->host_chunks = ranges;
     return CRF_OK;
 }
 
@@ -888,7 +896,7 @@ struct RangeScope {
     explicit RangeScope(crf_context* ctx) : c(ctx), table(ctx->d_member_table), voxels(ctx->num_voxels), vpt(ctx->max_vpt) {}
     void select(int j) {
         c->d_member_table = c->d_chunk_tables + size_t(j) * size_t(c->cs);
-        c->num_voxels = std::min(c->chunk_voxels, c->alloc_voxels - size_t(j) * c->chunk_voxels);
+        c->num_voxels = c->chunk_first[j + 1] - c->chunk_first[j];
     }
     ~RangeScope() {
         c->d_member_table = table;
@@ -896,6 +904,19 @@ struct RangeScope {
         c->max_vpt = vpt;
     }
 };
+
+// waits for an event by polling (a render thread blocked in calculateCpu has nothing else to do, and the sleeping wait
+// of the runtime costs tens of microseconds per range)
+hipError_t spin_on_event(hipEvent_t e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 1;; i++) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if ((i & 1023u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+            return hipEventSynchronize(e);
+        _mm_pause();
+    }
+}
 }  // namespace
 
 namespace crf {
@@ -910,59 +931,150 @@ int gather_reference_to(crf_context* c, bool secondary, int x, int y, int z, flo
     return CRF_OK;
 }
 
-// What calculateCpu(t, e, buffer) does, into the caller's host buffer (Calculator.hpp:123-124, VolumeData.cpp:1222-1226).
-// The reference-side preparation runs once; the per-voxel kernel is launched range by range on the context's stream and
-// each finished range is copied out on a second stream while the following ranges are still being evaluated, into
-// pages that a few host threads have faulted in meanwhile.
-int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out) {
+int reference_override(crf_context* owner, bool secondary, int x, int y, int z, RefOverride* out) {
+    if (int r = check_ready(owner)) return r;
+    if (secondary && owner->sec_members.empty()) return fail(owner, CRF_ERR_STATE, "no secondary members are bound");
+    if (int r = ref_voxel(owner, x, y, z, &out->voxel)) return r;
+    out->table = secondary ? owner->d_sec_table : owner->d_member_table;
+    return CRF_OK;
+}
+
+int compute_device_ex(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                      void* stream, const RefOverride* ov) {
+    if (!ov) return crf_compute_device(c, p, device_reference_values, device_out, stream);
+    if (!p || p->prepared_slot != 0) return fail(c, CRF_ERR_ARGUMENT, "a direct reference read cannot use a prepared slot");
+    const int rc = compute_impl(c, p, device_reference_values, device_out, stream, 3u, -1, ov);
+    if (rc == CRF_OK && (p->flags & CRF_FLAG_ABSOLUTE_VALUE)) {
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+        CRF_HIP(c, crf::launch_abs(static_cast<float*>(device_out), c->num_voxels, s));
+    }
+    return rc;
+}
+
+int prepare_device_ex(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream,
+                      const RefOverride* ov) {
+    if (slot < 0 || slot >= CRF_PREPARED_SLOTS)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("slot %d outside [0,%d)", slot, CRF_PREPARED_SLOTS));
+    return compute_impl(c, p, device_reference_values, nullptr, stream, 1u, slot, ov);
+}
+
+// What calculateCpu(t, e, buffer) does, into the caller's host buffer (Calculator.hpp:123-124, VolumeData.cpp:1222-1226):
+// the pipeline described above copy_result_to_host.  The reference-side preparation runs once, from the whole-grid
+// member table (the reference point indexes the whole grid); the per-voxel kernels run range by range.
+int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out,
+                    const RefOverride* ov) {
     if (int r = check_ready(c)) return r;
     if (!host_out || !p) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (int r = bind_device(c)) return r;
-    if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), c->alloc_voxels * sizeof(float)));
-    const bool ranged = !(p->flags & CRF_FLAG_SYMMETRIC) && p->prepared_slot == 0;
-    if (ranged)
-        if (int r = ensure_host_chunks(c)) return r;
-    if (!ranged || c->host_chunks <= 1) {
-        if (int r = crf_compute_device(c, p, device_reference_values, c->d_out, nullptr)) return r;
+    const size_t bytes = c->alloc_voxels * sizeof(float);
+    const bool ranged = !(p->flags & CRF_FLAG_SYMMETRIC) && p->prepared_slot == 0 && bytes >= (size_t(8) << 20) &&
+                        env_int_or("CRF_PLAIN_D2H", 0) != 1;
+    if (!ranged) {
+        if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), bytes));
+        if (int r = compute_device_ex(c, p, device_reference_values, c->d_out, nullptr, ov)) return r;
         return copy_result_to_host(c, c->d_out, host_out, c->alloc_voxels);
     }
-    const int chunks = c->host_chunks;
-    // pinned staging for the whole local result: the device -> host DMA of a range is then truly asynchronous, and the
-    // staging -> destination copy (with the destination's first-touch page faults) is spread over a few host threads
-    if (!c->h_staging) CRF_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_staging), c->alloc_voxels * sizeof(float), 0));
-    // 1. reference-side tables, once, from the whole-grid member table (the reference point indexes the whole grid)
-    if (int r = compute_impl(c, p, device_reference_values, nullptr, nullptr, 1u, -1)) return r;
-    // 2. per-voxel kernels, range by range
+    if (int r = ensure_host_ranges(c)) return r;
+    const int ranges = c->host_chunks;
+    // pinned, device-mapped staging for the whole local result
+    if (!c->h_staging) {
+        CRF_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_staging), bytes, hipHostMallocMapped));
+        void* dev = nullptr;
+        CRF_HIP(c, hipHostGetDevicePointer(&dev, c->h_staging, 0));
+        c->d_staging = static_cast<float*>(dev);
+    }
+    if (int r = ensure_copy_pool(c)) return r;
+    const char* path_env = getenv("CRF_HOST_PATH");
+    const bool dma = (path_env && strcmp(path_env, "dma") == 0) || (p->flags & CRF_FLAG_ABSOLUTE_VALUE);
+    if (dma && !c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), bytes));
+    if (!c->stream2) CRF_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    const bool two_streams = env_int_or("CRF_HOST_STREAMS", 2) == 2;
+    const int fault_mode = env_int_or("CRF_HOST_FAULT", 2);           // 0 none, 1 touch, 2 MADV_POPULATE_WRITE
+    const bool huge = env_int_or("CRF_HOST_HUGEPAGE", 1) == 1;        // ask for transparent huge pages first
+    const bool trace = env_int_or("CRF_HOST_TRACE", 0) == 1;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
+
+    // 0. host side first: the copier threads start faulting the destination in while the launches below are issued
+    char* dst = reinterpret_cast<char*>(host_out);
+    const char* src = reinterpret_cast<const char*>(c->h_staging);
+    if (huge && fault_mode != 0) {
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + (size_t(2) << 20) - 1) & ~((uintptr_t(2) << 20) - 1);
+        const uintptr_t e = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~((uintptr_t(2) << 20) - 1);
+        if (e > a) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);  // a hint; failure is harmless
+    }
+    for (int j = 0; j < ranges; j++) c->chunk_ready[j].store(0, std::memory_order_relaxed);
+    const int threads = c->copy_threads;
+    std::atomic<int>* ready = c->chunk_ready;
+    const size_t* first = c->chunk_first;
+    const std::function<int(int)> copy_job = [=](int w) -> int {
+        if (w >= threads) return 0;
+        int faulted = 0;  // ranges whose share this thread has faulted in already
+        for (int j = 0; j < ranges; j++) {
+            size_t lo, hi;
+            while (ready[j].load(std::memory_order_acquire) == 0) {
+                if (faulted < ranges) {
+                    thread_share(first[faulted] * sizeof(float), first[faulted + 1] * sizeof(float), w, threads, &lo, &hi);
+                    fault_in(dst, lo, hi, fault_mode);
+                    faulted++;
+                } else {
+                    _mm_pause();
+                }
+            }
+            if (ready[j].load(std::memory_order_acquire) < 0) return 0;  // the evaluation failed: nothing to copy
+            thread_share(first[j] * sizeof(float), first[j + 1] * sizeof(float), w, threads, &lo, &hi);
+            if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
+        }
+        return 0;
+    };
+    c->copy_pool->start(copy_job);
+    // every exit below has to release the copier threads first
+    auto abort_copy = [&](int rc) {
+        for (int j = 0; j < ranges; j++) c->chunk_ready[j].store(-1, std::memory_order_release);
+        c->copy_pool->wait();
+        return rc;
+    };
+
+    // 1. reference-side tables, once
+    if (int r = compute_impl(c, p, device_reference_values, nullptr, nullptr, 1u, -1, ov)) return abort_copy(r);
+    if (two_streams) {
+        if (hipEventRecord(c->prep_done, c->stream) != hipSuccess || hipStreamWaitEvent(c->stream2, c->prep_done, 0) != hipSuccess)
+            return abort_copy(fail(c, CRF_ERR_DEVICE, "ordering the second stream after the preparation failed"));
+    }
+    // 2. per-voxel kernels, range by range, alternating between two streams (the next range fills the GPU while the
+    //    last waves of the previous one drain); results go straight to the mapped staging buffer, or to HBM + DMA
+    float* out_base = dma ? c->d_out : c->d_staging;
     {
         RangeScope scope(c);
-        for (int j = 0; j < chunks; j++) {
+        for (int j = 0; j < ranges; j++) {
             scope.select(j);
-            float* out = c->d_out + size_t(j) * c->chunk_voxels;
-            if (int r = compute_impl(c, p, nullptr, out, nullptr, 2u, -1)) return r;
-            if (p->flags & CRF_FLAG_ABSOLUTE_VALUE) CRF_HIP(c, launch_abs(out, c->num_voxels, c->stream));
-            CRF_HIP(c, hipEventRecord(c->chunk_done[j], c->stream));
+            hipStream_t s = (two_streams && (j & 1)) ? c->stream2 : c->stream;
+            float* out = out_base + c->chunk_first[j];
+            if (int r = compute_impl(c, p, nullptr, out, s, 2u, -1)) return abort_copy(r);
+            if (p->flags & CRF_FLAG_ABSOLUTE_VALUE)
+                if (launch_abs(out, c->num_voxels, s) != hipSuccess) return abort_copy(fail(c, CRF_ERR_DEVICE, "launch_abs failed"));
+            if (hipEventRecord(c->chunk_done[j], s) != hipSuccess) return abort_copy(fail(c, CRF_ERR_DEVICE, "hipEventRecord failed"));
+            if (dma) {
+                const size_t off = c->chunk_first[j], count = c->chunk_first[j + 1] - off;
+                if (hipStreamWaitEvent(c->copy_stream, c->chunk_done[j], 0) != hipSuccess ||
+                    hipMemcpyAsync(c->h_staging + off, c->d_out + off, count * sizeof(float), hipMemcpyDeviceToHost,
+                                   c->copy_stream) != hipSuccess ||
+                    hipEventRecord(c->chunk_copied[j], c->copy_stream) != hipSuccess)
+                    return abort_copy(fail(c, CRF_ERR_DEVICE, "enqueueing the copy of a result range failed"));
+            }
         }
     }
-    // 3. DMA of each range into the staging buffer as soon as the range is done (second stream: the kernels of the
-    //    following ranges keep running) ...
-    for (int j = 0; j < chunks; j++) {
-        const size_t off = size_t(j) * c->chunk_voxels;
-        const size_t count = std::min(c->chunk_voxels, c->alloc_voxels - off);
-        CRF_HIP(c, hipStreamWaitEvent(c->copy_stream, c->chunk_done[j], 0));
-        CRF_HIP(c, hipMemcpyAsync(c->h_staging + off, c->d_out + off, count * sizeof(float), hipMemcpyDeviceToHost,
-                                  c->copy_stream));
-        CRF_HIP(c, hipEventRecord(c->chunk_copied[j], c->copy_stream));
+    const double t_issued = trace ? since() : 0.0;
+    // 3. release each range to the copier threads as it lands in the staging buffer
+    for (int j = 0; j < ranges; j++) {
+        const hipError_t e = spin_on_event(dma ? c->chunk_copied[j] : c->chunk_done[j]);
+        if (e != hipSuccess) return abort_copy(fail(c, CRF_ERR_DEVICE, fmt("waiting for result range %d failed: %s", j, hipGetErrorString(e))));
+        c->chunk_ready[j].store(1, std::memory_order_release);
+        if (trace) fprintf(stderr, "crf_compute: range %d (%zu voxels) landed at %.0f us\n", j, c->chunk_first[j + 1] - c->chunk_first[j], since());
     }
-    // 4. ... and staging -> caller's buffer by the copier threads, range by range as the DMAs land (the threads are
-    //    started only now: everything above is asynchronous, so their start-up hides behind the first range)
-    StagedCopier copier(c->h_staging, host_out, c->alloc_voxels, c->chunk_voxels, chunks);
-    copier.set_release_count(size_t(chunks));
-    for (int j = 0; j < chunks; j++) {
-        CRF_HIP(c, hipEventSynchronize(c->chunk_copied[j]));
-        copier.release(j);
-    }
-    copier.finish();
-    CRF_HIP(c, hipStreamSynchronize(c->stream));
+    c->copy_pool->wait();
+    if (trace) fprintf(stderr, "crf_compute: launches issued by %.0f us, copied out by %.0f us (%d ranges, %d copier threads)\n",
+                       t_issued, since(), ranges, threads);
     return CRF_OK;
 }
 

@@ -3,12 +3,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/corrfield.h"
 #include "crf_internal.h"
+#include "crf_pool.h"
 
 constexpr int kMaxHostChunks = 16;  // z-chunks of a host-output evaluation (kernel of chunk i+1 under the D2H of chunk i)
 
@@ -51,14 +54,22 @@ struct crf_context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
     std::string last_kernel;
     // host-output evaluations (crf_compute): the grid in up to kMaxHostChunks voxel ranges, one member-pointer table per
-    // range, so that the D2H copy of a finished range overlaps the kernels of the following ones
+    // range; the per-voxel kernel of a range stores into the pinned, device-mapped staging buffer and a pool of host
+    // threads moves finished ranges into the caller's buffer (api.cpp: compute_to_host)
     const float** d_chunk_tables = nullptr;  // host_chunks x cs pointers
     int host_chunks = 0;                     // 0: tables not built for the current members
-    size_t chunk_voxels = 0;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t chunk_done[kMaxHostChunks] = {};    // range evaluated (compute stream)
-    hipEvent_t chunk_copied[kMaxHostChunks] = {};  // range landed in the staging buffer (copy stream)
-    float* h_staging = nullptr;                    // pinned, alloc_voxels floats, lazily
+    size_t chunk_first[kMaxHostChunks + 1] = {};  // first voxel of every range; [host_chunks] = alloc_voxels
+    std::atomic<int> chunk_ready[kMaxHostChunks] = {};  // 1: range landed in the staging buffer, -1: evaluation failed
+    hipStream_t stream2 = nullptr;           // odd ranges (the next range fills the GPU while the previous one drains)
+    hipStream_t copy_stream = nullptr;       // DMA form only (CRF_HOST_PATH=dma, CRF_FLAG_ABSOLUTE_VALUE)
+    hipEvent_t prep_done = nullptr;
+    hipEvent_t chunk_done[kMaxHostChunks] = {};    // range evaluated
+    hipEvent_t chunk_copied[kMaxHostChunks] = {};  // DMA form: range landed in the staging buffer (copy stream)
+    float* h_staging = nullptr;                    // pinned + mapped, alloc_voxels floats, lazily
+    float* d_staging = nullptr;                    // its device address
+    std::unique_ptr<crf::SpinPool> copy_pool;      // copier threads, lazily
+    int copy_threads = 0;                          // how many of them a copy uses (calibrated at first use)
+    int copy_threads_cap = 0;                      // > 0: upper bound set by the owner (a device group shares the host)
     size_t alloc_voxels = 0;  // voxels of the whole local grid (num_voxels is narrowed while a chunk is being launched)
 };
 
@@ -68,7 +79,21 @@ namespace crf {
 // One evaluation straight into a caller-owned HOST buffer of the local grid: reference-side preparation once, then the
 // per-voxel kernel range by range with the D2H copies overlapped.  device_reference_values: device pointer to cs floats
 // or null (then params->reference_values / the reference point are used).
-int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out);
+// ref_override (crf_group, direct exchange): the reference-side preparation reads its cs values from table[c][voxel], the
+// member table of ANOTHER context (the slab that holds the reference point), instead of a vector or the local members.
+struct RefOverride {
+    const float* const* table = nullptr;
+    size_t voxel = 0;
+};
+int compute_to_host(crf_context* c, const crf_params* p, const void* device_reference_values, float* host_out,
+                    const RefOverride* ref_override);
+// crf_compute_device / crf_prepare_device with a direct reference read (ref_override may be null: the plain calls)
+int compute_device_ex(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                      void* stream, const RefOverride* ref_override);
+int prepare_device_ex(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream,
+                      const RefOverride* ref_override);
+// the override that makes other contexts read the reference values of local point (x, y, z) out of `owner`'s members
+int reference_override(crf_context* owner, bool secondary, int x, int y, int z, RefOverride* out);
 // referenceValues[c] = (secondary ? secondary members : members)[c][IDXS(x,y,z)] into a device buffer, stream-ordered
 int gather_reference_to(crf_context* c, bool secondary, int x, int y, int z, float* device_out, hipStream_t s);
 }  // namespace crf

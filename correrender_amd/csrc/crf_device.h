@@ -58,7 +58,8 @@ __device__ __forceinline__ float load_member(const float* base, uint32_t byte_of
 }
 
 __device__ __forceinline__ float load_ref(const RefSource& r, const float* const* __restrict__ members, int c) {
-    return r.values ? r.values[c] : members[c][r.voxel];
+    if (r.values) return r.values[c];
+    return (r.table ? r.table : members)[c][r.voxel];
 }
 
 // Compiler ordering fence on VALUES: an empty asm that "modifies" a and b makes everything computed from them

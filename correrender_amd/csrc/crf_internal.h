@@ -29,6 +29,10 @@ struct RefSource {
     // per-voxel kernel (reading d_prep).  Split so that a caller can prepare several evaluations ahead of time on
     // another stream (crf_prepare_device) and keep only the per-voxel kernels on the critical path.
     unsigned phase = 3;
+    // non-null: the fused gather reads table[c][voxel] instead of the launcher's own member table -- the member table of
+    // ANOTHER context whose slab holds the reference point (crf_group, direct exchange: same device, or a peer device
+    // whose memory this one may read over xGMI)
+    const float* const* table = nullptr;
     bool prepare() const { return (phase & 1u) != 0; }
     bool run() const { return (phase & 2u) != 0; }
 };

@@ -7,11 +7,18 @@
 //     volumes a slab of every member is one contiguous range and the result slabs concatenate in the caller's buffer);
 //   * every device has its own crf_context (members resident in ITS HBM, its own streams) and a persistent worker
 //     thread bound to it, so the launches of the N devices are issued concurrently, not one device after the other;
-//   * per evaluation there is ONE exchange: the device whose slab holds the reference point gathers the cs reference
-//     values and they are broadcast -- RCCL (ncclBroadcast over xGMI, one persistent single-process communicator from
-//     ncclCommInitAll, one rank per worker thread) when the ordinals are distinct, or a stream-ordered peer copy when a
-//     device ordinal repeats (rehearsal of an N-slab group on fewer GPUs: RCCL refuses two ranks on one device) or
-//     when CRF_GROUP_EXCHANGE=peer asks for it;
+//   * per evaluation there is ONE exchange: the cs values of the reference point live in the slab of one device (the
+//     owner).  With distinct ordinals the owner gathers them and they are broadcast -- RCCL (ncclBroadcast over xGMI, one
+//     persistent single-process communicator from ncclCommInitAll, one rank per worker thread).  When a device ordinal
+//     repeats (rehearsal of an N-slab group on fewer GPUs: RCCL refuses two ranks on one device) or CRF_GROUP_EXCHANGE=peer
+//     asks for it, the exchange is a DIRECT READ: every device's reference-side preparation kernel reads the cs values
+//     straight out of the owner's member volumes (peer access over xGMI) -- no copy, no event, no rendezvous between the
+//     workers; CRF_GROUP_EXCHANGE=copy (or a pair of devices without peer access) selects the staged form (owner
+//     gathers, the others hipMemcpyPeerAsync);
+//   * crf_group_compute_batch[_device] evaluates MANY reference points per hand-off: the reference vectors of up to 32
+//     points travel in one collective (owners fill their rows, one ncclAllReduce(sum)) or are read directly, the
+//     reference-side preparations of a block run first into prepared slots and its per-voxel kernels follow back to
+//     back; the workers synchronise once per call;
 //   * each device then runs the ranged evaluation of api.cpp (crf::compute_to_host) straight into its part of the
 //     caller's buffer: the D2H copies of the N devices run concurrently over their own PCIe links.
 // librccl is loaded on first use (dlopen): a single-device process never needs it.
@@ -33,17 +40,20 @@
 #include <vector>
 
 #include "crf_context.h"
+#include "crf_pool.h"
 
 namespace {
 
 // ---- the few RCCL entry points the exchange needs (rccl.h: ncclCommInitAll :236, ncclBroadcast :591) -------------
 using ncclComm_t = void*;
 constexpr int kNcclFloat32 = 7;  // ncclFloat32, rccl.h:466
+constexpr int kNcclSum = 0;      // ncclSum, rccl.h (ncclRedOp_t)
 struct Rccl {
     void* handle = nullptr;
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;  // rccl.h: ncclAllReduce
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
     bool load() {
@@ -61,9 +71,10 @@ struct Rccl {
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
         Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(handle, "ncclBroadcast"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !Broadcast) {
-            error = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclBroadcast";
+        if (!CommInitAll || !CommDestroy || !Broadcast || !AllReduce) {
+            error = "librccl lacks ncclCommInitAll / ncclCommDestroy / ncclBroadcast / ncclAllReduce";
             return false;
         }
         return true;
@@ -81,101 +92,6 @@ std::string fmt(const char* f, ...) {
 
 thread_local std::string g_group_create_error;
 
-// One persistent thread per device: run(job) hands the same job to every worker and returns when all are done.
-// Hand-off in both directions first SPINS for a short while (evaluations of an interactive session follow each other
-// within milliseconds, and a futex wake-up out of an idle state costs 50-150 us each way -- measured 0.28 ms per
-// evaluation with plain condition variables) and only then sleeps on a condition variable.
-class Workers {
-public:
-    explicit Workers(int n) : n_(n), status_(size_t(n), 0) {
-        for (int r = 0; r < n; r++) threads_.emplace_back([this, r] { loop(r); });
-    }
-    ~Workers() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-            generation_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    // returns the first non-zero status (by rank)
-    int run(const std::function<int(int)>& job) {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &job;
-            remaining_.store(n_, std::memory_order_relaxed);
-            generation_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        if (!spin_until([this] { return remaining_.load(std::memory_order_acquire) == 0; })) {
-            std::unique_lock<std::mutex> lk(m_);
-            done_cv_.wait(lk, [this] { return remaining_.load(std::memory_order_acquire) == 0; });
-        }
-        job_ = nullptr;
-        for (int s : status_)
-            if (s) return s;
-        return 0;
-    }
-    // rendezvous of all workers inside a job (every worker must call it the same number of times)
-    void barrier() {
-        std::unique_lock<std::mutex> lk(bm_);
-        const unsigned long gen = barrier_gen_;
-        if (++arrived_ == n_) {
-            arrived_ = 0;
-            barrier_gen_++;
-            bcv_.notify_all();
-        } else {
-            bcv_.wait(lk, [&] { return barrier_gen_ != gen; });
-        }
-    }
-
-private:
-    template <class Pred>
-    static bool spin_until(Pred done, double seconds = 300e-6) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0;; i++) {
-            if (done()) return true;
-            if ((i & 63) == 63 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
-                return false;
-            std::this_thread::yield();
-        }
-    }
-    void loop(int r) {
-        unsigned long seen = 0;
-        for (;;) {
-            if (!spin_until([&] { return generation_.load(std::memory_order_acquire) != seen; })) {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-            }
-            const std::function<int(int)>* job;
-            {
-                std::lock_guard<std::mutex> lk(m_);  // pairs with run(): job_ is published under the same lock
-                seen = generation_.load(std::memory_order_acquire);
-                if (stop_) return;
-                job = job_;
-            }
-            const int s = (*job)(r);
-            status_[size_t(r)] = s;
-            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-                std::lock_guard<std::mutex> lk(m_);
-                done_cv_.notify_all();
-            }
-        }
-    }
-    int n_;
-    std::vector<std::thread> threads_;
-    std::vector<int> status_;
-    std::mutex m_, bm_;
-    std::condition_variable cv_, done_cv_, bcv_;
-    const std::function<int(int)>* job_ = nullptr;
-    std::atomic<unsigned long> generation_{0};
-    std::atomic<int> remaining_{0};
-    unsigned long barrier_gen_ = 0;
-    int arrived_ = 0;
-    bool stop_ = false;
-};
-
 }  // namespace
 
 struct crf_group {
@@ -187,7 +103,9 @@ struct crf_group {
     std::vector<ncclComm_t> comms;       // RCCL communicators (empty: peer-copy exchange)
     Rccl rccl;
     std::string exchange = "none";
-    std::unique_ptr<Workers> workers;
+    std::unique_ptr<crf::SpinPool> workers;
+    bool direct = false;                 // peer exchange by direct reads of the owner's members (no copy, no host rendezvous)
+    std::vector<float*> d_rows;          // per device: kBatchRows x cs reference rows of a batch (RCCL / staged exchange), lazily
     int xs = 0, ys = 0, zs = 0, cs = 0;
     std::vector<int> z_begin, z_count;
     std::string err;
@@ -218,10 +136,12 @@ void slab(int zs, int n, int r, int* z0, int* zn) {  // the split of distributed
 
 void release_buffers(crf_group* g) {
     for (int r = 0; r < g->n; r++) {
-        if (g->d_refvec[size_t(r)]) {
+        if (g->d_refvec[size_t(r)] || g->d_rows[size_t(r)]) {
             (void)hipSetDevice(g->ordinals[size_t(r)]);
-            (void)hipFree(g->d_refvec[size_t(r)]);
+            if (g->d_refvec[size_t(r)]) (void)hipFree(g->d_refvec[size_t(r)]);
+            if (g->d_rows[size_t(r)]) (void)hipFree(g->d_rows[size_t(r)]);
             g->d_refvec[size_t(r)] = nullptr;
+            g->d_rows[size_t(r)] = nullptr;
         }
     }
 }
@@ -268,6 +188,7 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
     g->ordinals.assign(device_ordinals, device_ordinals + num_devices);
     g->ctx.assign(size_t(num_devices), nullptr);
     g->d_refvec.assign(size_t(num_devices), nullptr);
+    g->d_rows.assign(size_t(num_devices), nullptr);
     g->ref_ready.assign(size_t(num_devices), nullptr);
     g->z_begin.assign(size_t(num_devices), 0);
     g->z_count.assign(size_t(num_devices), 0);
@@ -280,6 +201,8 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
             crf_group_destroy(g);
             return rc;
         }
+        // the devices of a group share the host: bound each context's copier threads (host-output evaluations)
+        g->ctx[size_t(r)]->copy_threads_cap = std::max(2, 16 / num_devices);
         (void)hipSetDevice(device_ordinals[r]);
         if (hipEventCreateWithFlags(&g->ref_ready[size_t(r)], hipEventDisableTiming) != hipSuccess) {
             g_group_create_error = "crf_group_create: hipEventCreate failed";
@@ -290,8 +213,8 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
     }
     // the exchange: RCCL over xGMI when every slot has its own device
     const bool distinct = std::set<int>(g->ordinals.begin(), g->ordinals.end()).size() == size_t(num_devices);
-    const char* forced = getenv("CRF_GROUP_EXCHANGE");  // "peer" | "rccl"
-    const bool want_peer = forced && strcmp(forced, "peer") == 0;
+    const char* forced = getenv("CRF_GROUP_EXCHANGE");  // "peer" (direct reads) | "copy" (staged peer copy) | "rccl"
+    const bool want_peer = forced && (strcmp(forced, "peer") == 0 || strcmp(forced, "copy") == 0);
     if (num_devices == 1 && !(forced && strcmp(forced, "rccl") == 0)) {
         g->exchange = "none (one device)";
     } else if (distinct && !want_peer) {
@@ -311,21 +234,33 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
         }
         g->exchange = "rccl (ncclBroadcast, single-process communicator)";
     } else {
-        // peer copies: let every device read its peers' memory directly where the fabric allows it (errors ignored:
-        // hipMemcpyPeerAsync falls back to staging)
+        // peer exchange: let every device read its peers' memory where the fabric allows it.  When every pair can, the
+        // exchange is DIRECT: each device's reference-side preparation kernel reads the cs reference values straight
+        // out of the owner's member volumes (over xGMI, or locally when an ordinal repeats) -- no copy, no event, no
+        // rendezvous between the workers.  Otherwise the owner gathers and the others copy (staged, one rendezvous).
+        bool all_peers = true;
         for (int a = 0; a < num_devices; a++) {
             (void)hipSetDevice(g->ordinals[size_t(a)]);
             for (int b = 0; b < num_devices; b++) {
                 if (g->ordinals[size_t(a)] == g->ordinals[size_t(b)]) continue;
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, g->ordinals[size_t(a)], g->ordinals[size_t(b)]) == hipSuccess && can)
-                    (void)hipDeviceEnablePeerAccess(g->ordinals[size_t(b)], 0);
+                if (hipDeviceCanAccessPeer(&can, g->ordinals[size_t(a)], g->ordinals[size_t(b)]) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(g->ordinals[size_t(b)], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) all_peers = false;
+                } else {
+                    all_peers = false;
+                }
             }
         }
         (void)hipGetLastError();
-        g->exchange = distinct ? "peer copy (forced)" : "peer copy (a device ordinal repeats: rehearsal)";
+        const bool want_copy = forced && strcmp(forced, "copy") == 0;
+        g->direct = all_peers && !want_copy;
+        const char* why = distinct ? "forced" : "a device ordinal repeats: rehearsal";
+        g->exchange = g->direct ? fmt("peer read (direct gather from the owner's members; %s)", why)
+                                : fmt("peer copy (staged: owner gathers, the others copy; %s)", why);
     }
-    g->workers = std::make_unique<Workers>(num_devices);
+    // one persistent worker per device slot, bound to its device once
+    g->workers = std::make_unique<crf::SpinPool>(num_devices, [g](int r) { (void)hipSetDevice(g->ordinals[size_t(r)]); });
     *out_group = g;
     return CRF_OK;
 }
@@ -426,100 +361,260 @@ int crf_group_take_kernel_time(crf_group* g, double* out_ms_max, int* out_launch
     return CRF_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+constexpr int kBatchRows = crf::kMaxGatherRows;  // reference vectors exchanged per collective of a batch
+
+// Where the reference vector of one evaluation comes from, resolved once on the caller thread.
+struct RefPlan {
+    bool exchange = false;    // the reference point's values have to travel (not symmetric, no host vector)
+    int owner = -1;           // slot whose slab holds the reference point
+    int local_z = 0;          // its z inside that slab
+    crf::RefOverride direct;  // direct exchange: the owner's member table + the voxel inside the owner's slab
+};
+
+int plan_reference(crf_group* g, const crf_params* p, RefPlan* plan) {
+    if (p->prepared_slot != 0) return gfail(g, CRF_ERR_ARGUMENT, "prepared slots are per context, not per group");
+    const bool symmetric = (p->flags & CRF_FLAG_SYMMETRIC) != 0;
+    plan->exchange = !symmetric && p->reference_values == nullptr;
+    if (!plan->exchange) return CRF_OK;
+    if (p->ref_x < 0 || p->ref_y < 0 || p->ref_z < 0 || p->ref_x >= g->xs || p->ref_y >= g->ys || p->ref_z >= g->zs)
+        return gfail(g, CRF_ERR_ARGUMENT, fmt("reference point (%d,%d,%d) outside the grid %dx%dx%d", p->ref_x, p->ref_y,
+                                              p->ref_z, g->xs, g->ys, g->zs));
+    for (int r = 0; r < g->n; r++)
+        if (p->ref_z >= g->z_begin[size_t(r)] && p->ref_z < g->z_begin[size_t(r)] + g->z_count[size_t(r)]) {
+            plan->owner = r;
+            plan->local_z = p->ref_z - g->z_begin[size_t(r)];
+        }
+    if (g->direct) {
+        const bool from_secondary = (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY) != 0;
+        if (int rc = crf::reference_override(g->ctx[size_t(plan->owner)], from_secondary, p->ref_x, p->ref_y, plan->local_z,
+                                             &plan->direct))
+            return gfail(g, rc, crf_last_error(g->ctx[size_t(plan->owner)]));
+    }
+    return CRF_OK;
+}
+
+// Staged / RCCL exchange of ONE reference vector on slot r's stream; leaves it in g->d_refvec[r].  Every worker calls
+// its rank's collective even after a local error: the collective must be matched.
+int exchange_one(crf_group* g, int r, const crf_params* p, const RefPlan& plan) {
+    crf_context* c = g->ctx[size_t(r)];
+    float* mine = g->d_refvec[size_t(r)];
+    const bool from_secondary = (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY) != 0;
+    int rc = CRF_OK;
+    if (r == plan.owner) rc = crf::gather_reference_to(c, from_secondary, p->ref_x, p->ref_y, plan.local_z, mine, c->stream);
+    if (!g->comms.empty()) {
+        const int nrc = g->rccl.Broadcast(mine, mine, size_t(g->cs), kNcclFloat32, plan.owner, g->comms[size_t(r)], c->stream);
+        if (nrc != 0 && rc == CRF_OK) {
+            c->err = fmt("ncclBroadcast failed: %s", g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
+            rc = CRF_ERR_DEVICE;
+        }
+        return rc;
+    }
+    if (r == plan.owner && rc == CRF_OK && hipEventRecord(g->ref_ready[size_t(r)], c->stream) != hipSuccess) rc = CRF_ERR_DEVICE;
+    g->workers->barrier();  // the owner's event is recorded: the others may wait on it
+    if (r != plan.owner) {
+        if (hipStreamWaitEvent(c->stream, g->ref_ready[size_t(plan.owner)], 0) != hipSuccess ||
+            hipMemcpyPeerAsync(mine, g->ordinals[size_t(r)], g->d_refvec[size_t(plan.owner)], g->ordinals[size_t(plan.owner)],
+                               sizeof(float) * size_t(g->cs), c->stream) != hipSuccess) {
+            c->err = "peer copy of the reference vector failed";
+            if (rc == CRF_OK) rc = CRF_ERR_DEVICE;
+        }
+    }
+    // the owner must not overwrite its vector (next evaluation's gather) before the others have enqueued their copies
+    g->workers->barrier();
+    return rc;
+}
+
 // One evaluation over the whole grid: exchange of the reference vector, then every device evaluates its slab -- into its
 // part of the caller's HOST buffer (host_out != null: calculateCpu(t, e, buffer)) or into the caller's per-device DEVICE
 // buffers (device_outs[slot] receives the slab of that slot: xs*ys*z_count floats, resident for a device-side consumer).
-static int group_compute(crf_group* g, const crf_params* p, float* host_out, void* const* device_outs) {
-    if (!g || !p || (!host_out && !device_outs)) return gfail(g, CRF_ERR_ARGUMENT, "null argument");
+// `count` evaluations are handed to the workers in ONE job: for count > 1 (crf_group_compute_batch*) the reference
+// vectors of up to kBatchRows evaluations travel in one collective, the reference-side preparations of a block run
+// first (prepared slots) and its per-voxel kernels follow back to back; the workers synchronise once, at the end.
+int group_compute(crf_group* g, const crf_params* params, int count, float* const* host_outs, void* const* device_outs) {
+    if (!g || !params || count < 1 || (!host_outs && !device_outs)) return gfail(g, CRF_ERR_ARGUMENT, "null argument");
     if (g->cs <= 0) return gfail(g, CRF_ERR_STATE, "crf_group_set_grid has not been called");
-    if (p->prepared_slot != 0) return gfail(g, CRF_ERR_ARGUMENT, "prepared slots are per context, not per group");
-    if (device_outs)
-        for (int r = 0; r < g->n; r++)
-            if (!device_outs[r]) return gfail(g, CRF_ERR_ARGUMENT, fmt("device output of slot %d is a null pointer", r));
-    const bool symmetric = (p->flags & CRF_FLAG_SYMMETRIC) != 0;
-    const bool host_vector = p->reference_values != nullptr;
-    const bool needs_exchange = !symmetric && !host_vector;
-    int owner = -1, local_z = 0;
-    if (needs_exchange) {
-        if (p->ref_x < 0 || p->ref_y < 0 || p->ref_z < 0 || p->ref_x >= g->xs || p->ref_y >= g->ys || p->ref_z >= g->zs)
-            return gfail(g, CRF_ERR_ARGUMENT, fmt("reference point (%d,%d,%d) outside the grid %dx%dx%d", p->ref_x, p->ref_y,
-                                                  p->ref_z, g->xs, g->ys, g->zs));
-        for (int r = 0; r < g->n; r++)
-            if (p->ref_z >= g->z_begin[size_t(r)] && p->ref_z < g->z_begin[size_t(r)] + g->z_count[size_t(r)]) {
-                owner = r;
-                local_z = p->ref_z - g->z_begin[size_t(r)];
-            }
+    for (int i = 0; i < count; i++) {
+        if (host_outs && !host_outs[i]) return gfail(g, CRF_ERR_ARGUMENT, fmt("host output %d is a null pointer", i));
+        if (device_outs)
+            for (int r = 0; r < g->n; r++)
+                if (!device_outs[size_t(i) * size_t(g->n) + size_t(r)])
+                    return gfail(g, CRF_ERR_ARGUMENT, fmt("device output of evaluation %d, slot %d is a null pointer", i, r));
     }
+    std::vector<RefPlan> plans(static_cast<size_t>(count));
+    for (int i = 0; i < count; i++)
+        if (int rc = plan_reference(g, &params[i], &plans[size_t(i)])) return rc;
     const size_t slice = size_t(g->xs) * size_t(g->ys);
-    const bool from_secondary = (p->flags & CRF_FLAG_REFERENCE_FROM_SECONDARY) != 0;
     const bool use_rccl = !g->comms.empty();
-    const bool single = g->n == 1 && !use_rccl;
+    const bool single = g->n == 1 && !use_rccl;  // one slab: global == local coordinates, the context does it all itself
+    const bool batched = count > 1;
     const char* trace_env = getenv("CRF_GROUP_TRACE");  // development: host-side phase times of slot 0 on stderr
     const bool trace = trace_env && *trace_env == '1';
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
+
     const int status = g->workers->run([&](int r) -> int {
         const double t_start = since();
         crf_context* c = g->ctx[size_t(r)];
-        if (hipSetDevice(g->ordinals[size_t(r)]) != hipSuccess) return CRF_ERR_DEVICE;
-        crf_params local = *p;
-        local.flags &= ~CRF_FLAG_REFERENCE_FROM_SECONDARY;  // the reference vector arrives as a device array
-        const void* dref = nullptr;
         int rc = CRF_OK;
-        if (needs_exchange) {
-            float* mine = g->d_refvec[size_t(r)];
-            if (r == owner) rc = crf::gather_reference_to(c, from_secondary, p->ref_x, p->ref_y, local_z, mine, c->stream);
-            if (use_rccl) {
-                // every worker calls its rank's broadcast even after a local error: the collective must be matched
-                const int nrc = g->rccl.Broadcast(mine, mine, size_t(g->cs), kNcclFloat32, owner, g->comms[size_t(r)], c->stream);
-                if (nrc != 0 && rc == CRF_OK) {
-                    c->err = fmt("ncclBroadcast failed: %s", g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
-                    rc = CRF_ERR_DEVICE;
-                }
-            } else if (!single) {
-                if (r == owner && rc == CRF_OK && hipEventRecord(g->ref_ready[size_t(r)], c->stream) != hipSuccess)
-                    rc = CRF_ERR_DEVICE;
-                g->workers->barrier();  // the owner's event is recorded: the others may wait on it
-                if (r != owner) {
-                    if (hipStreamWaitEvent(c->stream, g->ref_ready[size_t(owner)], 0) != hipSuccess ||
-                        hipMemcpyPeerAsync(mine, g->ordinals[size_t(r)], g->d_refvec[size_t(owner)],
-                                           g->ordinals[size_t(owner)], sizeof(float) * size_t(g->cs), c->stream) != hipSuccess) {
-                        c->err = "peer copy of the reference vector failed";
-                        if (rc == CRF_OK) rc = CRF_ERR_DEVICE;
+        auto note = [&](int e) {
+            if (e != CRF_OK && rc == CRF_OK) rc = e;
+        };
+        // what slot r hands to its context for evaluation i: parameters, a device vector or a direct-read override
+        auto local_params = [&](int i) {
+            crf_params local = params[i];
+            if (!single) local.flags &= ~CRF_FLAG_REFERENCE_FROM_SECONDARY;  // the vector arrives / is read remotely
+            return local;
+        };
+        if (batched && (use_rccl || (!g->direct && !single)) && !g->d_rows[size_t(r)])
+            if (hipMalloc(reinterpret_cast<void**>(&g->d_rows[size_t(r)]), sizeof(float) * size_t(kBatchRows) * size_t(g->cs)) !=
+                hipSuccess) {
+                c->err = "hipMalloc of the batch's reference rows failed";
+                note(CRF_ERR_DEVICE);  // keep going: the collectives below must still be matched (they will fail alike)
+            }
+        for (int b0 = 0; b0 < count; b0 += kBatchRows) {
+            const int bn = std::min(kBatchRows, count - b0);
+            // ---- 1. exchange of the block's reference vectors ------------------------------------------------------
+            std::vector<const void*> dref(static_cast<size_t>(bn), nullptr);
+            std::vector<const crf::RefOverride*> ov(static_cast<size_t>(bn), nullptr);
+            if (!single) {
+                if (g->direct) {
+                    for (int j = 0; j < bn; j++)
+                        if (plans[size_t(b0 + j)].exchange) ov[size_t(j)] = &plans[size_t(b0 + j)].direct;
+                } else if (!batched) {
+                    if (plans[0].exchange) {
+                        note(exchange_one(g, r, &params[0], plans[0]));
+                        dref[0] = g->d_refvec[size_t(r)];
+                    }
+                } else if (use_rccl) {
+                    // owners fill their rows (zeros elsewhere), one all-reduce(sum) gives every device every row
+                    float* rows = g->d_rows[size_t(r)];
+                    int32_t xyz[3 * kBatchRows];
+                    bool any = false, secondary = false;
+                    for (int j = 0; j < bn; j++) {
+                        const RefPlan& pl = plans[size_t(b0 + j)];
+                        const crf_params& p = params[b0 + j];
+                        const bool mine = pl.exchange && pl.owner == r;
+                        xyz[3 * j] = p.ref_x;
+                        xyz[3 * j + 1] = p.ref_y;
+                        xyz[3 * j + 2] = mine ? pl.local_z : -1;
+                        any = any || pl.exchange;
+                        secondary = secondary || (pl.exchange && (p.flags & CRF_FLAG_REFERENCE_FROM_SECONDARY));
+                    }
+                    if (any && rows) {
+                        if (secondary) {  // rows from the secondary field: one gather per such row, the rest zero-filled first
+                            if (hipMemsetAsync(rows, 0, sizeof(float) * size_t(bn) * size_t(g->cs), c->stream) != hipSuccess)
+                                note(CRF_ERR_DEVICE);
+                            for (int j = 0; j < bn; j++) {
+                                const RefPlan& pl = plans[size_t(b0 + j)];
+                                if (!pl.exchange || pl.owner != r) continue;
+                                const bool sec = (params[b0 + j].flags & CRF_FLAG_REFERENCE_FROM_SECONDARY) != 0;
+                                note(crf::gather_reference_to(c, sec, params[b0 + j].ref_x, params[b0 + j].ref_y, pl.local_z,
+                                                              rows + size_t(j) * size_t(g->cs), c->stream));
+                            }
+                        } else {
+                            note(crf_gather_reference_rows_device(c, xyz, bn, rows, nullptr));
+                        }
+                        const int nrc = g->rccl.AllReduce(rows, rows, size_t(bn) * size_t(g->cs), kNcclFloat32, kNcclSum,
+                                                          g->comms[size_t(r)], c->stream);
+                        if (nrc != 0 && rc == CRF_OK) {
+                            c->err = fmt("ncclAllReduce failed: %s", g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
+                            rc = CRF_ERR_DEVICE;
+                        }
+                        for (int j = 0; j < bn; j++)
+                            if (plans[size_t(b0 + j)].exchange) dref[size_t(j)] = rows + size_t(j) * size_t(g->cs);
                     }
                 }
             }
-            dref = mine;
-            if (rc != CRF_OK) return rc;
-        }
-        const double t_exchanged = since();
-        int rc2;
-        if (host_out) {
-            rc2 = crf::compute_to_host(c, &local, dref, host_out + slice * size_t(g->z_begin[size_t(r)]));
-        } else {
-            rc2 = crf_compute_device(c, &local, dref, device_outs[r], nullptr);
-            if (rc2 == CRF_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
-                c->err = "hipStreamSynchronize failed after the evaluation";
-                rc2 = CRF_ERR_DEVICE;
+            const double t_exchanged = since();
+            // ---- 2. evaluation -------------------------------------------------------------------------------------
+            if (!batched) {
+                crf_params local = local_params(0);
+                if (rc == CRF_OK) {
+                    if (host_outs) {
+                        note(crf::compute_to_host(c, &local, dref[0], host_outs[0] + slice * size_t(g->z_begin[size_t(r)]), ov[0]));
+                    } else {
+                        note(crf::compute_device_ex(c, &local, dref[0], device_outs[r], nullptr, ov[0]));
+                    }
+                }
+            } else if (!g->direct && !single && !use_rccl) {
+                // staged peer copies (no direct access between some pair of devices): one exchange per evaluation
+                for (int j = 0; j < bn; j++) {
+                    const int i = b0 + j;
+                    crf_params local = local_params(i);
+                    const void* vec = nullptr;
+                    if (plans[size_t(i)].exchange) {
+                        note(exchange_one(g, r, &params[i], plans[size_t(i)]));
+                        vec = g->d_refvec[size_t(r)];
+                    }
+                    if (rc != CRF_OK) continue;
+                    if (host_outs) note(crf::compute_to_host(c, &local, vec, host_outs[i] + slice * size_t(g->z_begin[size_t(r)]), nullptr));
+                    else note(crf::compute_device_ex(c, &local, vec, device_outs[size_t(i) * size_t(g->n) + size_t(r)], nullptr, nullptr));
+                }
+            } else if (host_outs) {
+                for (int j = 0; j < bn && rc == CRF_OK; j++) {
+                    const int i = b0 + j;
+                    crf_params local = local_params(i);
+                    note(crf::compute_to_host(c, &local, dref[size_t(j)], host_outs[i] + slice * size_t(g->z_begin[size_t(r)]),
+                                              ov[size_t(j)]));
+                }
+            } else if (rc == CRF_OK) {
+                // reference-side preparations of the block first (tiny kernels), then its per-voxel kernels back to back
+                const int slot0 = (b0 / kBatchRows) % 2 * kBatchRows;
+                for (int j = 0; j < bn && rc == CRF_OK; j++) {
+                    crf_params local = local_params(b0 + j);
+                    if (local.flags & CRF_FLAG_SYMMETRIC) continue;  // no reference side
+                    note(crf::prepare_device_ex(c, &local, dref[size_t(j)], slot0 + j, nullptr, ov[size_t(j)]));
+                }
+                for (int j = 0; j < bn && rc == CRF_OK; j++) {
+                    const int i = b0 + j;
+                    crf_params local = local_params(i);
+                    if (!(local.flags & CRF_FLAG_SYMMETRIC)) local.prepared_slot = slot0 + j + 1;
+                    note(crf_compute_device(c, &local, nullptr, device_outs[size_t(i) * size_t(g->n) + size_t(r)], nullptr));
+                }
             }
+            if (trace && r == 0)
+                fprintf(stderr, "crf_group slot 0: job started %.0f us after the call, exchange of block %d issued by %.0f us, "
+                                "evaluations issued by %.0f us\n", t_start, b0 / kBatchRows, t_exchanged, since());
         }
-        if (trace && r == 0)
-            fprintf(stderr, "crf_group_compute slot 0: job started %.0f us after the call, exchange issued by %.0f us, done %.0f us\n",
-                    t_start, t_exchanged, since());
-        return rc2;
+        // the host-output path returns synchronised; device-resident results: one synchronisation per job
+        if (!host_outs && hipStreamSynchronize(c->stream) != hipSuccess) {
+            c->err = "hipStreamSynchronize failed after the evaluation";
+            note(CRF_ERR_DEVICE);
+        }
+        return rc;
     });
-    if (trace) fprintf(stderr, "crf_group_compute: returned to the caller after %.0f us\n", since());
-    return collect(g, status, host_out ? "crf_group_compute" : "crf_group_compute_device");
+    if (trace) fprintf(stderr, "crf_group: returned to the caller after %.0f us\n", since());
+    return collect(g, status, host_outs ? "crf_group_compute" : "crf_group_compute_device");
 }
+
+}  // namespace
+
+extern "C" {
 
 int crf_group_compute(crf_group* g, const crf_params* p, float* host_out) {
     if (!host_out) return gfail(g, CRF_ERR_ARGUMENT, "null output");
-    return group_compute(g, p, host_out, nullptr);
+    return group_compute(g, p, 1, &host_out, nullptr);
 }
 
 int crf_group_compute_device(crf_group* g, const crf_params* p, void* const* device_outs) {
     if (!device_outs) return gfail(g, CRF_ERR_ARGUMENT, "null output table");
-    return group_compute(g, p, nullptr, device_outs);
+    return group_compute(g, p, 1, nullptr, device_outs);
+}
+
+int crf_group_compute_batch(crf_group* g, const crf_params* params, int count, float* const* host_outs) {
+    if (!host_outs) return gfail(g, CRF_ERR_ARGUMENT, "null output table");
+    if (count == 0) return CRF_OK;
+    return group_compute(g, params, count, host_outs, nullptr);
+}
+
+int crf_group_compute_batch_device(crf_group* g, const crf_params* params, int count, void* const* device_outs) {
+    if (!device_outs) return gfail(g, CRF_ERR_ARGUMENT, "null output table");
+    if (count == 0) return CRF_OK;
+    return group_compute(g, params, count, nullptr, device_outs);
 }
 
 }  // extern "C"

@@ -481,6 +481,54 @@ class CorrFieldGroup:
         del keep
         return outs
 
+    def _batch_params(self, measure, refs, kw):
+        """crf_params array for a list of reference points (GLOBAL coordinates), all with the same settings."""
+        if not refs:
+            raise ValueError("empty batch")
+        mode_kw = {k: kw.pop(k, False) for k in ("symmetric", "reference_from_secondary", "absolute_value")}
+        flags, mode = CorrField._mode_flags(**mode_kw)
+        minmax_ref, minmax_query = CorrField._binned_ranges(self, measure, kw.pop("minmax_ref", None),
+                                                            kw.pop("minmax_query", None), mode)
+        arr = (CrfParams * len(refs))()
+        keep = []
+        for i, ref in enumerate(refs):
+            p, k = CorrField._params(self, measure, ref, kw.get("k"), kw.get("kraskov_estimator_index", 1),
+                                     kw.get("num_bins", 80), minmax_ref, minmax_query, None, flags)
+            arr[i] = p
+            keep.append(k)
+        return arr, keep
+
+    def compute_batch(self, measure, refs, *, outs=None, **kw):
+        """crf_group_compute_batch: one hand-off for a list of reference points; returns a list of (zs, ys, xs) arrays."""
+        arr, keep = self._batch_params(measure, list(refs), kw)
+        xs, ys, zs = self.grid
+        if outs is None:
+            outs = [np.empty((zs, ys, xs), dtype=np.float32) for _ in range(len(arr))]
+        if len(outs) != len(arr) or any(o.dtype != np.float32 or o.size != xs * ys * zs or not o.flags["C_CONTIGUOUS"]
+                                        for o in outs):
+            raise ValueError("outs: one C-contiguous float32 array of xs*ys*zs elements per reference point")
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        self._check(self._lib.crf_group_compute_batch(self._g, arr, len(arr), ptrs))
+        del keep
+        return outs
+
+    def compute_batch_device(self, measure, refs, outs, **kw):
+        """crf_group_compute_batch_device: outs[i][slot] is a CUDA float32 tensor on the slot's device holding the slab
+        of evaluation i; returns when every device has finished the whole list."""
+        arr, keep = self._batch_params(measure, list(refs), kw)
+        n = len(self.devices)
+        if len(outs) != len(arr) or any(len(row) != n for row in outs):
+            raise ValueError("outs: one row of per-slot tensors per reference point")
+        xs, ys, _ = self.grid
+        for row in outs:
+            for slot, t in enumerate(row):
+                if not t.is_cuda or not t.is_contiguous() or t.element_size() != 4 or t.numel() != xs * ys * self.slab(slot)[1]:
+                    raise ValueError(f"output of slot {slot} must be a contiguous CUDA float32 tensor of the slab's size")
+        ptrs = (C.c_void_p * (len(arr) * n))(*[t.data_ptr() for row in outs for t in row])
+        self._check(self._lib.crf_group_compute_batch_device(self._g, arr, len(arr), ptrs))
+        del keep
+        return outs
+
     def set_profiling(self, enabled: bool):
         self._check(self._lib.crf_group_set_profiling(self._g, 1 if enabled else 0))
 

@@ -120,7 +120,8 @@ void crf_destroy(crf_context* ctx);
 /* Last error message of this context (or of the calling thread's last failed crf_create when ctx==NULL). */
 const char* crf_last_error(const crf_context* ctx);
 /* ABI version of this header, bumped on incompatible change. */
-int crf_abi_version(void);  /* 4: crf_group_* (several devices behind one caller thread), crf_set_kraskov_noise;
+int crf_abi_version(void);  /* 5: crf_group_compute_batch[_device], crf_member_minmax_divergent;
+                               4: crf_group_* (several devices behind one caller thread), crf_set_kraskov_noise;
                                3: crf_params.reserved[0] became prepared_slot (same layout; 0 keeps the old meaning) */
 
 /* ---- the ensemble (replaces the fields[] gather of CorrelationCalculator.cpp:791-800) --------------------- */
@@ -135,6 +136,12 @@ int crf_bind_members_device(crf_context* ctx, const void* const* device_members)
  * top of VolumeData::getMinMaxScalarFieldValue, VolumeData.cpp:1632-1670); computed on the device, cached until
  * the members change. */
 int crf_member_minmax(crf_context* ctx, float* out_min, float* out_max);
+/* The same extrema for a field the reference flags as DIVERGENT (VolumeData::getIsScalarFieldDivergent,
+ * VolumeData.cpp:616-621: the field named "Helicity"): getMinMaxScalarFieldValue centres its range at zero,
+ * min = -max|.|, max = +max|.| (VolumeData.cpp:1661-1666), per member -- and the min of the mins / max of the maxes the
+ * calculator takes (CorrelationCalculator.cpp:822-829) is then -A / +A with A = max(|min|, |max|) over all members.
+ * secondary != 0: the secondary members.  The caller decides whether a field is divergent (it knows the field's name). */
+int crf_member_minmax_divergent(crf_context* ctx, int secondary, float* out_min, float* out_max);
 /* The second scalar field of the SEPARATE / SEPARATE_SYMMETRIC field modes (fieldIndex2Gui; fieldEntriesSecondary,
  * CorrelationCalculator.cpp:1182-1229): cs volumes of the same local grid, uploaded or borrowed like the primary
  * members; dropped by crf_set_grid.  Used by CRF_FLAG_SYMMETRIC / CRF_FLAG_REFERENCE_FROM_SECONDARY. */
@@ -191,8 +198,8 @@ int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* d
  * own HBM and is driven by its own worker thread inside the library, and every evaluation has one exchange step: the
  * device whose slab holds the reference point gathers the cs reference values (CorrelationCalculator.cpp:802,815-817)
  * and broadcasts them -- ncclBroadcast on a persistent single-process RCCL communicator over xGMI when the ordinals
- * are distinct, a stream-ordered peer copy when an ordinal repeats (a rehearsal of N slabs on fewer GPUs) or when the
- * environment says CRF_GROUP_EXCHANGE=peer.  Each device then evaluates its slab and copies it straight into its part
+ * are distinct; when an ordinal repeats (a rehearsal of N slabs on fewer GPUs) or the environment says
+ * CRF_GROUP_EXCHANGE=peer, every device reads the cs values directly out of the owner's member volumes (peer access).  Each device then evaluates its slab and copies it straight into its part
  * of the caller's buffer (the copies of the N devices run concurrently).  Results are bit-identical to a single
  * context's.  Same conventions as above: one caller thread, status codes, crf_group_last_error. */
 typedef struct crf_group crf_group;
@@ -222,6 +229,16 @@ int crf_group_compute(crf_group* group, const crf_params* params, float* host_ou
  * buffer on the device of that slot and receives the slot's slab, xs*ys*z_count floats (crf_group_slab); returns when
  * every device has finished.  For consumers that keep the field on the GPUs. */
 int crf_group_compute_device(crf_group* group, const crf_params* params, void* const* device_outs);
+/* MANY reference points per call -- a diagram or an animation that evaluates a list of points (the reference's
+ * HEBChart / time-series consumers call calculateCpu point after point from the same thread): params[i] as for
+ * crf_group_compute, evaluation i writes host_outs[i] (xs*ys*zs floats each).  One hand-off to the device workers for
+ * the whole list; the reference vectors of up to 32 points travel in ONE collective (owners fill their rows, one
+ * ncclAllReduce(sum)) or are read directly from the owner's members (peer exchange). */
+int crf_group_compute_batch(crf_group* group, const crf_params* params, int count, float* const* host_outs);
+/* ... with device-resident results: device_outs[i * crf_group_size(group) + slot] receives the slab of slot `slot` of
+ * evaluation i.  Per device the reference-side preparations of a block of evaluations run first, the per-voxel kernels
+ * follow back to back and the workers synchronise once, at the end of the call. */
+int crf_group_compute_batch_device(crf_group* group, const crf_params* params, int count, void* const* device_outs);
 int crf_group_set_profiling(crf_group* group, int enabled);
 /* Slowest device's summed kernel time (ms) and its launch count since the last call. */
 int crf_group_take_kernel_time(crf_group* group, double* out_ms_max, int* out_launches);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/corrfield.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "python binding table and header diverge"
-    assert lib.crf_abi_version() == 4
+    assert lib.crf_abi_version() == 5
 
 
 def test_params_struct_layout_matches_header(tmp_path):

@@ -173,3 +173,44 @@ def test_group_device_resident_results(engine):
                 assert_bit_exact(got, engine.compute(measure, ref), f"group device outputs {measure.name} {ref}")
         with pytest.raises(ValueError):
             grp.compute_device(Measure.PEARSON, outs[:2], (0, 0, 0))
+
+
+@pytest.mark.parametrize("exchange", ["peer", "copy", "rccl1"])
+def test_group_batch_equals_single_evaluations(engine, monkeypatch, exchange):
+    """crf_group_compute_batch[_device]: many reference points per hand-off (one exchange per block of 32, preparations
+    first, kernels back to back) -- bit-identical to one evaluation at a time, for every exchange form that can be
+    rehearsed on one card: direct peer reads, staged peer copies, and a 1-rank RCCL all-reduce."""
+    import torch
+    xs, ys, zs, cs = 20, 12, 10, 24
+    ens = synth.box_ensemble(xs, ys, zs, cs, seed=21)
+    sec = synth.normal_ensemble(xs, ys, zs, cs, seed=22)
+    engine.set_grid(xs, ys, zs, cs)
+    engine.upload_members(ens)
+    engine.upload_secondary_members(sec)
+    devices = [0] if exchange == "rccl1" else [0, 0, 0]
+    monkeypatch.setenv("CRF_GROUP_EXCHANGE", "rccl" if exchange == "rccl1" else exchange)
+    rng = np.random.default_rng(5)
+    refs = [(int(rng.integers(0, xs)), int(rng.integers(0, ys)), int(rng.integers(0, zs))) for _ in range(70)]  # 3 blocks
+    with ca.CorrFieldGroup(devices) as grp:
+        assert {"peer": "peer read", "copy": "peer copy", "rccl1": "rccl"}[exchange] in grp.exchange
+        grp.set_grid(xs, ys, zs, cs)
+        grp.upload_members(ens)
+        grp.upload_secondary_members(sec)
+        n = len(devices)
+        for measure in (Measure.PEARSON, Measure.SPEARMAN, Measure.MUTUAL_INFORMATION_BINNED, Measure.MUTUAL_INFORMATION_KRASKOV):
+            outs = [[torch.empty(xs * ys * grp.slab(s)[1], dtype=torch.float32, device="cuda") for s in range(n)]
+                    for _ in refs]
+            grp.compute_batch_device(measure, refs, outs, k=2)
+            for ref, row in zip(refs, outs):
+                assert_bit_exact(torch.cat(row).cpu().numpy(), engine.compute(measure, ref, k=2),
+                                 f"batch device {exchange} {measure.name} {ref}")
+        got = grp.compute_batch(Measure.KENDALL, refs[:5])
+        for ref, field in zip(refs[:5], got):
+            assert_bit_exact(field, engine.compute(Measure.KENDALL, ref), f"batch host {exchange} {ref}")
+        # SEPARATE mode in a batch: the rows come from the secondary field
+        got = grp.compute_batch(Measure.PEARSON, refs[:4], reference_from_secondary=True)
+        for ref, field in zip(refs[:4], got):
+            assert_bit_exact(field, engine.compute(Measure.PEARSON, ref, reference_from_secondary=True),
+                             f"batch host, reference from the secondary field, {exchange} {ref}")
+        with pytest.raises(ca.CorrFieldError, match="outside"):
+            grp.compute_batch(Measure.PEARSON, [(0, 0, 0), (0, 0, zs)])

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--measure", default="pearson")
     ap.add_argument("--devices", nargs="*", default=["0", "0,0", "0,0,0,0"])
     ap.add_argument("--reps", type=int, default=15)
+    ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
     xs, ys, zs = args.grid
     cs = args.members
@@ -47,7 +48,25 @@ def main():
         eng.upload_members(ens)
         want = eng.compute(measure, pts[-1], **kw).copy()
         m, lo = run(lambda p: eng.compute(measure, p, out=out, **kw))
-        print(json.dumps({"path": "single context (crf_compute)", "ms_median": m, "ms_min": lo}), flush=True)
+        import torch
+        dev_out = torch.empty(xs * ys * zs, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for p in pts[:3]:
+            eng.compute_device(measure, dev_out, p, stream=stream, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for p in pts[3:]:
+            eng.compute_device(measure, dev_out, p, stream=stream, **kw)
+        torch.cuda.synchronize()
+        back_to_back = (time.perf_counter() - t0) / len(pts[3:])
+        eng.set_profiling(True)
+        eng.compute_device(measure, dev_out, pts[0], stream=stream, **kw)
+        torch.cuda.synchronize()
+        kernel_ms, _ = eng.take_kernel_time()
+        eng.set_profiling(False)
+        print(json.dumps({"path": "single context (crf_compute)", "ms_median": m, "ms_min": lo,
+                          "device_resident_back_to_back_ms": round(back_to_back * 1e3, 4),
+                          "kernel_ms_hip_events": round(kernel_ms, 4)}), flush=True)
     for spec in args.devices:
         devices = [int(d) for d in spec.split(",")]
         with ca.CorrFieldGroup(devices) as grp:
@@ -59,8 +78,24 @@ def main():
             outs = [torch.empty(xs * ys * grp.slab(s)[1], dtype=torch.float32, device=f"cuda:{d}")
                     for s, d in enumerate(devices)]
             md, lod = run(lambda p: grp.compute_device(measure, outs, p, **kw))
+            # the batch call: B reference points per hand-off, amortised time per evaluation
+            B = args.batch
+            rows = [outs] * B          # every evaluation into the same buffers: only the timing matters here
+            bt = []
+            for rep in range(5):
+                refs = [pts[(rep * B + i) % len(pts)] for i in range(B)]
+                t0 = time.perf_counter()
+                grp.compute_batch_device(measure, refs, rows, **kw)
+                bt.append((time.perf_counter() - t0) / B)
+            grp.set_profiling(True)
+            grp.compute_device(measure, outs, pts[0], **kw)
+            kernel_ms, launches = grp.take_kernel_time()
+            grp.set_profiling(False)
             print(json.dumps({"path": f"crf_group over devices {devices}", "exchange": grp.exchange, "ms_median": m,
                               "ms_min": lo, "device_resident_ms_median": md, "device_resident_ms_min": lod,
+                              f"batch{B}_device_resident_ms_per_evaluation_median": round(med(bt) * 1e3, 4),
+                              f"batch{B}_device_resident_ms_per_evaluation_min": round(min(bt) * 1e3, 4),
+                              "slowest_slot_kernel_ms_when_profiled": round(kernel_ms, 4),
                               "bit_identical_to_single_context": same}), flush=True)
 
 

@@ -52,7 +52,8 @@ def one():
     torch.cuda.synchronize()
     dev = (time.perf_counter() - t0) / n
     med = lambda v: sorted(v)[len(v) // 2]
-    print(json.dumps({"chunks": os.environ.get("CRF_HOST_CHUNKS", "auto"), "threads": os.environ.get("CRF_COPY_THREADS", "auto"),
+    print(json.dumps({"variant": os.environ.get("CRF_VARIANT_NAME", "default"),
+                      "chunks": os.environ.get("CRF_HOST_CHUNKS", "auto"), "threads": os.environ.get("CRF_COPY_THREADS", "auto"),
                       "resident_ms": round(med(t_res) * 1e3, 3), "resident_min_ms": round(min(t_res) * 1e3, 3),
                       "fresh_ms": round(med(t_fresh) * 1e3, 3), "device_only_ms": round(dev * 1e3, 3)}))
 
@@ -74,6 +75,20 @@ if __name__ == "__main__":
         dt = (time.perf_counter() - t0) / 10
         print(json.dumps({"pure_dma_d2h_pinned_ms": round(dt * 1e3, 3), "GB/s": round(d.numel() * 4 / dt / 1e9, 1)}))
         del d, h
-        for chunks, threads in [("1", "8"), ("8", "4"), ("8", "8"), ("16", "4"), ("16", "8"), ("16", "12")]:
-            env = dict(os.environ, CRF_HOST_CHUNKS=chunks, CRF_COPY_THREADS=threads)
+        variants = [
+            ("default (mapped staging, shrinking ranges, 2 streams, populate + THP)", {}),
+            ("one stream", {"CRF_HOST_STREAMS": "1"}),
+            ("no huge pages", {"CRF_HOST_HUGEPAGE": "0"}),
+            ("touch instead of populate", {"CRF_HOST_FAULT": "1"}),
+            ("no pre-faulting", {"CRF_HOST_FAULT": "0"}),
+            ("dma engine instead of mapped stores", {"CRF_HOST_PATH": "dma"}),
+            ("8 equal ranges", {"CRF_HOST_CHUNKS": "8"}),
+            ("16 equal ranges", {"CRF_HOST_CHUNKS": "16"}),
+            ("4 copier threads", {"CRF_COPY_THREADS": "4"}),
+            ("8 copier threads", {"CRF_COPY_THREADS": "8"}),
+            ("16 copier threads", {"CRF_COPY_THREADS": "16"}),
+            ("plain: kernel, then one hipMemcpy", {"CRF_PLAIN_D2H": "1"}),
+        ]
+        for name, extra in variants:
+            env = dict(os.environ, CRF_VARIANT_NAME=name, **extra)
             subprocess.run([sys.executable, __file__, "one"], env=env, check=True)
