@@ -905,18 +905,6 @@ struct RangeScope {
     }
 };
 
-// waits for an event by polling (a render thread blocked in calculateCpu has nothing else to do, and the sleeping wait
-// of the runtime costs tens of microseconds per range)
-hipError_t spin_on_event(hipEvent_t e) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned i = 1;; i++) {
-        const hipError_t q = hipEventQuery(e);
-        if (q != hipErrorNotReady) return q;
-        if ((i & 1023u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
-            return hipEventSynchronize(e);
-        _mm_pause();
-    }
-}
 }  // namespace
 
 namespace crf {
@@ -1067,7 +1055,7 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
     const double t_issued = trace ? since() : 0.0;
     // 3. release each range to the copier threads as it lands in the staging buffer
     for (int j = 0; j < ranges; j++) {
-        const hipError_t e = spin_on_event(dma ? c->chunk_copied[j] : c->chunk_done[j]);
+        const hipError_t e = crf::spin_on_event(dma ? c->chunk_copied[j] : c->chunk_done[j]);
         if (e != hipSuccess) return abort_copy(fail(c, CRF_ERR_DEVICE, fmt("waiting for result range %d failed: %s", j, hipGetErrorString(e))));
         c->chunk_ready[j].store(1, std::memory_order_release);
         if (trace) fprintf(stderr, "crf_compute: range %d (%zu voxels) landed at %.0f us\n", j, c->chunk_first[j + 1] - c->chunk_first[j], since());

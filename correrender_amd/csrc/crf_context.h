@@ -76,6 +76,18 @@ struct crf_context {
 
 // api.cpp internals used by the device group (group.cpp)
 namespace crf {
+// waits for an event by polling hipEventQuery (a render thread blocked in calculateCpu has nothing else to do, and the
+// runtime's sleeping wait costs tens of microseconds per wake-up); falls back to hipEventSynchronize after 50 ms
+inline hipError_t spin_on_event(hipEvent_t e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 1;; i++) {
+        const hipError_t q = hipEventQuery(e);
+        if (q != hipErrorNotReady) return q;
+        if ((i & 1023u) == 0u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+            return hipEventSynchronize(e);
+        _mm_pause();
+    }
+}
 // One evaluation straight into a caller-owned HOST buffer of the local grid: reference-side preparation once, then the
 // per-voxel kernel range by range with the D2H copies overlapped.  device_reference_values: device pointer to cs floats
 // or null (then params->reference_values / the reference point are used).

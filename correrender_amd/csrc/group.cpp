@@ -453,6 +453,8 @@ int group_compute(crf_group* g, const crf_params* params, int count, float* cons
     const bool batched = count > 1;
     const char* trace_env = getenv("CRF_GROUP_TRACE");  // development: host-side phase times of slot 0 on stderr
     const bool trace = trace_env && *trace_env == '1';
+    const char* sync_env = getenv("CRF_GROUP_SYNC");
+    const bool stream_sync = sync_env && strcmp(sync_env, "stream") == 0;
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
 
@@ -580,10 +582,16 @@ int group_compute(crf_group* g, const crf_params* params, int count, float* cons
                 fprintf(stderr, "crf_group slot 0: job started %.0f us after the call, exchange of block %d issued by %.0f us, "
                                 "evaluations issued by %.0f us\n", t_start, b0 / kBatchRows, t_exchanged, since());
         }
-        // the host-output path returns synchronised; device-resident results: one synchronisation per job
-        if (!host_outs && hipStreamSynchronize(c->stream) != hipSuccess) {
-            c->err = "hipStreamSynchronize failed after the evaluation";
-            note(CRF_ERR_DEVICE);
+        // the host-output path returns synchronised; device-resident results: one synchronisation per job, by polling
+        // the slot's event (CRF_GROUP_SYNC=stream: hipStreamSynchronize)
+        if (!host_outs) {
+            const bool ok = stream_sync ? hipStreamSynchronize(c->stream) == hipSuccess
+                                        : (hipEventRecord(g->ref_ready[size_t(r)], c->stream) == hipSuccess &&
+                                           crf::spin_on_event(g->ref_ready[size_t(r)]) == hipSuccess);
+            if (!ok) {
+                c->err = "synchronisation failed after the evaluation";
+                note(CRF_ERR_DEVICE);
+            }
         }
         return rc;
     });

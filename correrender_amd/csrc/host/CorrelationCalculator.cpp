@@ -66,6 +66,26 @@ void ICorrelationCalculator::setReferencePoint(const std::array<int, 3>& referen
     }
 }
 
+void ICorrelationCalculator::setReferencePointFromWorld(const std::array<float, 3>& worldPosition) {
+    const std::array<int, 3> maxCoord{volumeData->getGridSizeX() - 1, volumeData->getGridSizeY() - 1,
+                                      volumeData->getGridSizeZ() - 1};
+    const AABB3& gridAabb = volumeData->getBoundingBoxRendering();
+    std::array<int, 3> referencePointNew{};
+    for (int i = 0; i < 3; i++) {
+        // float arithmetic in the reference's order: (p - min) / (max - min), times maxCoord, glm::round, int cast, clamp
+        float position = (worldPosition[i] - gridAabb.min[i]) / (gridAabb.max[i] - gridAabb.min[i]);
+        position *= float(maxCoord[i]);
+        const float rounded = std::round(position);  // glm::round: half away from zero
+        // a one-cell axis gives 0/0: the reference converts that NaN to int (undefined behaviour, INT_MIN on x86-64)
+        // and clamps it to 0
+        referencePointNew[i] = std::isnan(rounded) ? 0 : std::clamp(int(std::clamp(rounded, -2.0e9f, 2.0e9f)), 0, maxCoord[i]);
+    }
+    if (referencePointIndex != referencePointNew) {
+        referencePointIndex = referencePointNew;
+        dirty = true;
+    }
+}
+
 // Settings keys of ICorrelationCalculator (the reference's keys and value spellings, CorrelationCalculator.cpp:397-565):
 // the field mode comes first because it decides which field-index keys apply.
 const SettingBinding<ICorrelationCalculator> ICorrelationCalculator::kSettings[] = {

@@ -46,6 +46,9 @@ public:
     FieldType getOutputFieldType() override { return FieldType::SCALAR; }
     int getInputFieldIndex() const { return fieldIndex; }
     void setReferencePoint(const std::array<int, 3>& referencePoint);
+    /// World position (a picking hit on the volume's rendering box) -> nearest grid point, clamped
+    /// (CorrelationCalculator.cpp:204-217).
+    void setReferencePointFromWorld(const std::array<float, 3>& worldPosition);
     const std::array<int, 3>& getReferencePoint() const { return referencePointIndex; }
     bool getIsEnsembleMode() const { return isEnsembleMode; }
     int getCorrelationMemberCount() const;

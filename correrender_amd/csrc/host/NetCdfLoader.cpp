@@ -2,6 +2,9 @@
 // magic numrecs dim_list gatt_list var_list; all integers big-endian, names and values padded to 4 bytes).
 #include "NetCdfLoader.hpp"
 
+#include <algorithm>
+#include <map>
+
 #include <dlfcn.h>
 
 #include <cmath>
@@ -184,6 +187,79 @@ void NetCdfLoader::openWithLibrary(const char* why) {
     }
 }
 
+// NetCDF-4 through the built-in HDF5 decoder: the netCDF-4 data model on top of HDF5 objects ("NetCDF-4/HDF5 file
+// format", netcdf-c docs/file_format_specifications.md):
+//   dimension  = a dimension-scale dataset (attribute CLASS = "DIMENSION_SCALE") named like the dimension; its NAME
+//                attribute starts with "This is a netCDF dimension but not a netCDF variable." when no coordinate
+//                variable of that name exists; _Netcdf4Dimid orders the dimensions;
+//   variable   = every other dataset (and the coordinate variables); its dimensions are the scales its DIMENSION_LIST
+//                attribute refers to (object references); datasets without one get anonymous dimensions, as in nc_open.
+void NetCdfLoader::openWithHdf5Reader() {
+    if (file) std::fclose(file);
+    file = nullptr;
+    hdf5 = std::make_unique<Hdf5File>(path);
+    const std::string notAVariable = "This is a netCDF dimension but not a netCDF variable.";
+    const auto& sets = hdf5->datasets();
+    // 1. dimensions, ordered by _Netcdf4Dimid where present (else by appearance)
+    struct Scale {
+        int dimid;
+        size_t order;
+        const Hdf5Dataset* ds;
+    };
+    std::vector<Scale> scales;
+    for (size_t i = 0; i < sets.size(); i++) {
+        if (!sets[i].isDimensionScale() || sets[i].shape.size() != 1) continue;
+        int dimid = 1 << 30;
+        auto it = sets[i].attributes.find("_Netcdf4Dimid");
+        if (it != sets[i].attributes.end() && it->second.isNumeric && !it->second.numbers.empty()) dimid = int(it->second.numbers[0]);
+        scales.push_back(Scale{dimid, i, &sets[i]});
+    }
+    std::stable_sort(scales.begin(), scales.end(), [](const Scale& a, const Scale& b) { return a.dimid < b.dimid; });
+    std::map<uint64_t, int> dimOfHeader;
+    for (const Scale& s : scales) {
+        dimOfHeader[s.ds->headerAddress] = int(dims.size());
+        dims.push_back(Dim{s.ds->name, s.ds->shape[0]});
+    }
+    // 2. variables
+    for (size_t i = 0; i < sets.size(); i++) {
+        const Hdf5Dataset& ds = sets[i];
+        if (ds.isDimensionScale()) {
+            auto it = ds.attributes.find("NAME");
+            if (it != ds.attributes.end() && it->second.isString && it->second.text.compare(0, notAVariable.size(), notAVariable) == 0)
+                continue;  // a dimension without a coordinate variable
+        }
+        Var v;
+        v.name = ds.name;
+        v.varid = int(i);
+        v.type = ds.type.cls == Hdf5Datatype::FLOAT ? (ds.type.size == 4 ? NC_FLOAT : ds.type.size == 8 ? NC_DOUBLE : 0) : 0;
+        auto list = ds.attributes.find("DIMENSION_LIST");
+        for (size_t d = 0; d < ds.shape.size(); d++) {
+            int dimid = -1;
+            if (ds.isDimensionScale() && ds.shape.size() == 1) {
+                dimid = dimOfHeader.at(ds.headerAddress);  // a coordinate variable is its own dimension
+            } else if (list != ds.attributes.end() && d < list->second.references.size()) {
+                auto hit = dimOfHeader.find(list->second.references[d]);
+                if (hit != dimOfHeader.end() && dims[size_t(hit->second)].length == ds.shape[d]) dimid = hit->second;
+            }
+            if (dimid < 0) {  // no scale attached: an anonymous dimension of this length (nc_open names them phony_dim_N)
+                dimid = int(dims.size());
+                dims.push_back(Dim{"phony_dim_" + std::to_string(dimid), ds.shape[d]});
+            }
+            v.dimids.push_back(dimid);
+        }
+        auto sn = ds.attributes.find("standard_name");
+        if (sn != ds.attributes.end() && sn->second.isString) v.standardName = sn->second.text;
+        for (const char* fill : {"missing_value", "_FillValue"}) {  // the later one wins, as in the classic path
+            auto a = ds.attributes.find(fill);
+            if (a != ds.attributes.end() && a->second.isNumeric && a->second.type.cls == Hdf5Datatype::FLOAT && !a->second.numbers.empty()) {
+                v.hasFill = true;
+                v.fillValue = float(a->second.numbers[0]);
+            }
+        }
+        vars.push_back(std::move(v));
+    }
+}
+
 void NetCdfLoader::error(const std::string& msg) const {
     throw CalculatorError("Error in NetCdfLoader: " + msg + " (file \"" + path + "\").");
 }
@@ -195,7 +271,7 @@ NetCdfLoader::~NetCdfLoader() {
 
 uint64_t NetCdfLoader::dimLength(int dimid) const {
     const Dim& d = dims.at(size_t(dimid));
-    return (d.length == 0 && !library) ? numRecs : d.length;
+    return (d.length == 0 && !library && !hdf5) ? numRecs : d.length;
 }
 
 NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
@@ -204,7 +280,31 @@ NetCdfLoader::NetCdfLoader(const std::string& filePath) : path(filePath) {
     unsigned char magic[4] = {0, 0, 0, 0};
     if (std::fread(magic, 1, 4, file) != 4) error("truncated header");
     if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') {
-        openWithLibrary("NetCDF-4 (an HDF5 container)");
+        // NetCDF-4 = an HDF5 container.  Default: the built-in decoder (Hdf5Reader, no library needed).  netcdf-c takes
+        // over when CRF_LIBNETCDF names it or CRF_NETCDF_BACKEND=library asks for it, and as the fallback for whatever the
+        // decoder does not read (it says which feature).
+        const char* backend = std::getenv("CRF_NETCDF_BACKEND");
+        const bool wantLibrary = std::getenv("CRF_LIBNETCDF") != nullptr || (backend && std::string(backend) == "library");
+        if (wantLibrary) {
+            openWithLibrary("NetCDF-4 (an HDF5 container)");
+        } else {
+            try {
+                openWithHdf5Reader();
+            } catch (const Hdf5Error& e) {
+                const std::string why = e.what();
+                hdf5.reset();
+                dims.clear();
+                vars.clear();
+                try {
+                    openWithLibrary("NetCDF-4 (an HDF5 container)");
+                } catch (const CalculatorError&) {
+                    error("the built-in HDF5 decoder could not read this NetCDF-4 file (" + why +
+                          ") and the netcdf-c library is not available (install libnetcdf or set CRF_LIBNETCDF, or convert the "
+                          "file with `nccopy -k classic`)");
+                }
+                warnings.push_back("built-in HDF5 decoder: " + why + "; read through netcdf-c instead");
+            }
+        }
     } else if (magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F' && magic[3] == 5) {
         openWithLibrary("CDF-5 (64-bit data)");
     } else {
@@ -367,6 +467,22 @@ void NetCdfLoader::deriveGridAndFields() {
 // one xs*ys*zs slab: the whole variable (rank 3) or index `leadingIndex` of its first dimension (rank 4)
 void NetCdfLoader::readSlab(const Var& v, uint64_t leadingIndex, float* out) const {
     const uint64_t n = uint64_t(xs) * uint64_t(ys) * uint64_t(zs);
+    if (hdf5) {
+        const Hdf5Dataset& ds = hdf5->datasets().at(size_t(v.varid));
+        const bool lead = v.dimids.size() == 4;
+        if (lead && leadingIndex >= dimLength(v.dimids[0])) error("index outside the leading dimension of \"" + v.name + "\"");
+        std::vector<uint64_t> start(ds.shape.size(), 0), count(ds.shape);
+        if (lead) {
+            start[0] = leadingIndex;
+            count[0] = 1;
+        }
+        try {
+            hdf5->readFloats(ds, start, count, out);
+        } catch (const Hdf5Error& e) {
+            error(std::string("reading \"") + v.name + "\" failed: " + e.what());
+        }
+        return;
+    }
     if (library) {  // netcdf-c converts NC_DOUBLE to float itself (the reference's loadFloatArray3D/4D, :93-120)
         const bool lead = v.dimids.size() == 4;
         if (lead && leadingIndex >= dimLength(v.dimids[0])) error("index outside the leading dimension of \"" + v.name + "\"");

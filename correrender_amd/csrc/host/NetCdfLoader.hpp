@@ -3,16 +3,18 @@
 // (scripts/generate_synth_box_ensembles.py:151-158) and read by its NetCdfLoader
 // (src/Loaders/NetCdfLoader.cpp:286-560 setInputFiles, :826-935 getFieldEntry).
 //
-// Two back ends behind one metadata model:
+// Three back ends behind one metadata model:
 //   * the CLASSIC file formats are parsed directly, without any library: CDF-1 (32-bit offsets) and CDF-2 (64-bit
 //     offsets), fixed-size and record (UNLIMITED first dimension) variables, NC_FLOAT / NC_DOUBLE data;
 //   * NetCDF-4 files (HDF5 containers -- what the generator's `format='NETCDF4_CLASSIC'` writes and what the paper's data
-//     sets are) and CDF-5 go through the netcdf-c library the reference itself links (nc_open ... nc_get_vara_float,
-//     NetCdfLoader.cpp:282-339, 826-935), loaded at RUN TIME with dlopen: every machine that runs the reference has
-//     it.  Library name: $CRF_LIBNETCDF, else libnetcdf.so[.19|.18|.15|.13|.11|.7].  Without the library such a file is
-//     rejected with a message that says so and names the conversion (`nccopy -k classic`).  This build image has
-//     neither libnetcdf nor libhdf5 nor any NetCDF-4 file, so that path is exercised against a test double of the
-//     library's C API only (tests/fake_libnetcdf.c) -- see INTEGRATION.md.
+//     sets are) are decoded by Hdf5Reader (this directory: superblocks 0-3, old- and new-style groups, contiguous /
+//     chunked / compressed float and double variables, dimension scales), with no library at all; pinned against files
+//     written by the real libhdf5 (tests/golden/netcdf4/);
+//   * the netcdf-c library the reference itself links (nc_open ... nc_get_vara_float, NetCdfLoader.cpp:282-339,
+//     826-935), loaded at RUN TIME with dlopen, reads CDF-5 and is the fallback for whatever HDF5 feature the decoder
+//     does not cover; it is used FIRST when CRF_LIBNETCDF names it (or CRF_NETCDF_BACKEND=library).  Library name:
+//     $CRF_LIBNETCDF, else libnetcdf.so[.19|.18|.15|.13|.11|.7].  This image has no libnetcdf, so that back end is
+//     exercised against a test double of the library's C API (tests/fake_libnetcdf.c) -- see INTEGRATION.md.
 //
 // Conventions kept from the reference loader:
 //   * the grid is taken from the first floating-point variable with 3 or 4 dimensions whose trailing dimensions are
@@ -29,6 +31,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+
+#include "Hdf5Reader.hpp"
 
 namespace crfhost {
 
@@ -79,6 +83,7 @@ private:
         float fillValue;
     };
 
+    std::unique_ptr<Hdf5File> hdf5;  // non-null: the file is read by the built-in HDF5 decoder (Var::varid = dataset index)
     struct Library;  // the netcdf-c entry points resolved with dlsym (NetCdfLoader.cpp)
     std::string path;
     mutable FILE* file = nullptr;
@@ -95,6 +100,7 @@ private:
 
     void parseClassicHeader();
     void openWithLibrary(const char* why);
+    void openWithHdf5Reader();
     void deriveGridAndFields();
     uint64_t dimLength(int dimid) const;
     void readSlab(const Var& v, uint64_t leadingIndex, float* out) const;

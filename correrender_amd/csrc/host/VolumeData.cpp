@@ -1,10 +1,22 @@
 #include "VolumeData.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
 
 namespace crfhost {
+
+void VolumeData::setGridExtent(float dx, float dy, float dz) {
+    box.min = {0.0f, 0.0f, 0.0f};
+    box.max = {float(xs - 1) * dx, float(ys - 1) * dy, float(zs - 1) * dz};
+    const float maxDimension = std::max(box.max[0], std::max(box.max[1], box.max[2]));
+    for (int i = 0; i < 3; i++) {
+        const float normalizedDimension = box.max[i] / maxDimension;
+        boxRendering.min[i] = -normalizedDimension * 0.25f;
+        boxRendering.max[i] = normalizedDimension * 0.25f;
+    }
+}
 
 void VolumeData::setFieldData(const std::string& fieldName, int timeStepIdx, int ensembleIdx, const float* values) {
     const size_t n = getSlice3dEntryCount();
@@ -65,6 +77,12 @@ std::pair<float, float> VolumeData::getMinMaxScalarFieldValue(const std::string&
     for (size_t i = 0; i < entry->getNumEntries(); i++) {
         if (v[i] < mn) mn = v[i];
         if (v[i] > mx) mx = v[i];
+    }
+    // Is this a divergent scalar field? If yes, the range is centred at zero (VolumeData.cpp:1661-1666).
+    if (getIsScalarFieldDivergent(fieldName)) {
+        const float maxAbs = std::max(std::abs(mn), std::abs(mx));
+        mn = -maxAbs;
+        mx = maxAbs;
     }
     fieldMinMaxCache[access] = {mn, mx};
     return {mn, mx};

@@ -7,10 +7,14 @@
 //       calc->calculateCpu(t, e, buffer) and wrapping the buffer in a HostCacheEntry that later delete[]s it
 //       (Cache/HostCacheEntry.hpp:39-50) -- the callee must neither retain nor free the buffer;
 //   getMinMaxScalarFieldValue(name, t, e)         VolumeData.cpp:1632-1670 (per (field,t,e) extrema, cached);
+//       -- symmetrised to +-max|.| for a field flagged divergent (getIsScalarFieldDivergent, :616-621, :1661-1666);
+//   getBoundingBoxRendering()                     VolumeData.hpp:205, computed by setGridExtent (VolumeData.cpp:322-330):
+//       the world-space box picking positions are expressed in (ICorrelationCalculator::setReferencePointFromWorld);
 //   addCalculator                                  VolumeData.cpp:1046-1086 (initialize, id, setVolumeData(this,true),
 //       registered under getOutputFieldName()).
 // No loaders, no device caches, no rendering: inputs are handed in as arrays.
 #pragma once
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -39,9 +43,21 @@ private:
 };
 typedef std::shared_ptr<HostCacheEntryType> HostCacheEntry;
 
+/// Axis-aligned box with float corners (the two members of sgl::AABB3 the path reads).
+struct AABB3 {
+    std::array<float, 3> min{0.f, 0.f, 0.f}, max{0.f, 0.f, 0.f};
+};
+
 class VolumeData {
 public:
-    VolumeData(int xs, int ys, int zs, int ts, int es) : xs(xs), ys(ys), zs(zs), ts(ts), es(es) {}
+    VolumeData(int xs, int ys, int zs, int ts, int es) : xs(xs), ys(ys), zs(zs), ts(ts), es(es) { setGridExtent(1.f, 1.f, 1.f); }
+
+    /// Cell spacing -> box = [0, (n-1) d] and the rendering box: the box's dimensions divided by the largest one,
+    /// times -+0.25 (VolumeData::setGridExtent, VolumeData.cpp:322-330).
+    void setGridExtent(float dx, float dy, float dz);
+    const AABB3& getBoundingBoxRendering() const { return boxRendering; }
+    /// VolumeData.cpp:616-621: only the field named "Helicity" is centred at zero.
+    bool getIsScalarFieldDivergent(const std::string& fieldName) const { return fieldName == "Helicity"; }
 
     int getGridSizeX() const { return xs; }
     int getGridSizeY() const { return ys; }
@@ -69,6 +85,7 @@ public:
 private:
     typedef std::tuple<std::string, int, int> Access;
     int xs, ys, zs, ts, es;
+    AABB3 box, boxRendering;
     std::vector<std::string> fieldNames;
     std::map<Access, HostCacheEntry> storage;         // input fields
     std::map<Access, HostCacheEntry> hostFieldCache;  // calculator outputs

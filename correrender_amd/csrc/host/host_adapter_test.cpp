@@ -36,7 +36,8 @@ static std::shared_ptr<VolumeData> makeVolume(int xs, int ys, int zs, int ts, in
     for (int f = 0; f < nfields; f++)
         for (int t = 0; t < ts; t++)
             for (int e = 0; e < es; e++) {
-                vol->setFieldData(f == 0 ? "data" : "data" + std::to_string(f + 1), t, e,
+                // the third field carries the one name the reference treats as divergent (VolumeData.cpp:616-621)
+                vol->setFieldData(f == 0 ? "data" : f == 2 ? "Helicity" : "data" + std::to_string(f + 1), t, e,
                                   data ? data->data() + off : zeros.data());
                 off += n;
             }
@@ -114,6 +115,43 @@ static int testSettings() {
     (void)calc->getIsDirty();
     calc->setReferencePoint({100, -5, 3});
     CHECK((calc->getReferencePoint() == std::array<int, 3>{31, 0, 3}) && calc->getIsDirtyDontReset());
+    // setReferencePointFromWorld (CorrelationCalculator.cpp:204-217): the rendering box of a 32 x 24 x 16 grid with unit
+    // spacing is +-0.25 * (31, 23, 15) / 31 (VolumeData.cpp:322-330); its centre is the middle of the index range
+    {
+        const AABB3& b = vol->getBoundingBoxRendering();
+        CHECK(b.min[0] == -0.25f && b.max[0] == 0.25f);
+        CHECK(b.max[1] == (23.0f / 31.0f) * 0.25f && b.min[2] == -(15.0f / 31.0f) * 0.25f);
+        (void)calc->getIsDirty();
+        calc->setReferencePointFromWorld({0.0f, 0.0f, 0.0f});
+        CHECK((calc->getReferencePoint() == std::array<int, 3>{16, 12, 8}));  // round(15.5), round(11.5), round(7.5): half away from zero
+        CHECK(calc->getIsDirtyDontReset());
+        (void)calc->getIsDirty();
+        calc->setReferencePointFromWorld({0.0f, 0.0f, 0.0f});
+        CHECK(!calc->getIsDirtyDontReset());                                    // unchanged point: not dirty
+        calc->setReferencePointFromWorld({b.min[0], b.max[1], b.min[2]});
+        CHECK((calc->getReferencePoint() == std::array<int, 3>{0, 23, 0}));
+        calc->setReferencePointFromWorld({10.0f, -10.0f, b.max[2] * 0.5f});    // outside the box: clamped
+        CHECK((calc->getReferencePoint() == std::array<int, 3>{31, 0, 11}));   // z: 0.75 * 15 = 11.25
+        // anisotropic spacing changes the box, not the mapping of its corners
+        vol->setGridExtent(1.0f, 2.0f, 0.5f);
+        const AABB3& b2 = vol->getBoundingBoxRendering();
+        CHECK(b2.max[1] == 0.25f && b2.max[0] == (31.0f / 46.0f) * 0.25f);
+        calc->setReferencePointFromWorld({b2.max[0], b2.max[1], b2.max[2]});
+        CHECK((calc->getReferencePoint() == std::array<int, 3>{31, 23, 15}));
+        vol->setGridExtent(1.0f, 1.0f, 1.0f);
+    }
+    // divergent fields: getMinMaxScalarFieldValue centres the range at zero (VolumeData.cpp:616-621, 1661-1666)
+    {
+        VolumeData small(2, 2, 1, 1, 2);
+        const float a[4] = {-1.0f, 0.5f, 2.0f, 0.0f}, b4[4] = {-3.5f, 0.0f, 1.0f, 1.5f};
+        small.setFieldData("Helicity", 0, 0, a);
+        small.setFieldData("Helicity", 0, 1, b4);
+        small.setFieldData("data", 0, 0, a);
+        CHECK(small.getIsScalarFieldDivergent("Helicity") && !small.getIsScalarFieldDivergent("data"));
+        CHECK(small.getMinMaxScalarFieldValue("Helicity", 0, 0) == std::make_pair(-2.0f, 2.0f));
+        CHECK(small.getMinMaxScalarFieldValue("Helicity", 0, 1) == std::make_pair(-3.5f, 3.5f));
+        CHECK(small.getMinMaxScalarFieldValue("data", 0, 0) == std::make_pair(-1.0f, 2.0f));
+    }
     // second calculator of the same type gets a numbered name
     auto calc2 = std::make_shared<CorrelationCalculator>(0);
     vol->addCalculator(calc2);
@@ -211,6 +249,13 @@ static int testCompute(const char* inPath, const std::string& outDir, const char
         eval("kendall_symmetric", tFixed, 0);
         calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_binned"}});
         eval("binned_symmetric", tFixed, 0);
+    }
+    if (nf > 2) {  // a divergent field: the binned-MI range is centred at zero (VolumeData.cpp:1661-1666)
+        calc->setSettings(SettingsMap{{"correlation_measure_type", "mi_binned"}, {"correlation_field_mode", "Single"}});
+        calc->setSettings(SettingsMap{{"scalar_field_idx", "2"}});
+        calc->setReferencePoint({1, 2, 3});
+        eval("binned_helicity", tFixed, 0);
+        calc->setSettings(SettingsMap{{"scalar_field_idx", "0"}});
     }
     {  // the sibling ensemble calculators on the first field
         auto mean = std::make_shared<EnsembleMeanCalculator>(0);

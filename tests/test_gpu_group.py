@@ -25,7 +25,7 @@ def test_group_equals_single_context_all_measures(engine, slots):
     engine.set_grid(xs, ys, zs, cs)
     engine.upload_members(ens)
     with ca.CorrFieldGroup([0] * slots) as grp:
-        assert "peer copy" in grp.exchange
+        assert "peer read" in grp.exchange
         grp.set_grid(xs, ys, zs, cs)
         covered = []
         for s in range(slots):

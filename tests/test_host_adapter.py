@@ -109,3 +109,21 @@ def test_calculate_cpu_time_mode(tmp_path, oracle):
     assert_bit_exact(out("m_pearson"), oracle.field(oracle_lib.PEARSON, a, refc), "time-mode pearson")
     assert_bit_exact(out("m_kendall"), oracle.field(oracle_lib.KENDALL, a, refc), "time-mode kendall")
     assert_close(out("m_mi_kraskov"), oracle.field(oracle_lib.MI_KRASKOV, a, refc, k=default_kraskov_k(cs)), "time-mode ksg")
+
+
+@pytest.mark.gpu
+def test_calculate_cpu_divergent_field_range(tmp_path, oracle):
+    """A field named "Helicity" is divergent in the reference: getMinMaxScalarFieldValue centres its range at zero
+    (VolumeData.cpp:616-621, 1661-1666), which changes the binned-MI normalisation (CorrelationCalculator.cpp:820-846)."""
+    xs, ys, zs, cs = 16, 12, 6, 16
+    a = synth.box_ensemble(xs, ys, zs, cs, seed=61)
+    h = synth.normal_ensemble(xs, ys, zs, cs, seed=62) + 0.75          # asymmetric range
+    data = np.stack([a[None], a[None] * 2.0, h[None]])                 # [nf=3, ts=1, es, z, y, x]
+    out = _run_compute(tmp_path, data)
+    mn, mx = oracle.minmax(h)
+    m = max(abs(mn), abs(mx))
+    ref = h[:, 3, 2, 1].copy()
+    want = oracle.field(oracle_lib.MI_BINNED, h, ref, num_bins=80, minmax_ref=(-m, m))
+    assert_close(out("binned_helicity"), want, "binned MI on a divergent field")
+    plain = oracle.field(oracle_lib.MI_BINNED, h, ref, num_bins=80, minmax_ref=(mn, mx))
+    assert not np.array_equal(want, plain)                             # the symmetrised range matters
