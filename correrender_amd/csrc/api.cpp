@@ -919,6 +919,13 @@ int gather_reference_to(crf_context* c, bool secondary, int x, int y, int z, flo
     return CRF_OK;
 }
 
+int second_stream(crf_context* c, hipStream_t* out) {
+    if (int r = bind_device(c)) return r;
+    if (!c->stream2) CRF_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    *out = c->stream2;
+    return CRF_OK;
+}
+
 int reference_override(crf_context* owner, bool secondary, int x, int y, int z, RefOverride* out) {
     if (int r = check_ready(owner)) return r;
     if (secondary && owner->sec_members.empty()) return fail(owner, CRF_ERR_STATE, "no secondary members are bound");
@@ -975,7 +982,10 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
     const char* path_env = getenv("CRF_HOST_PATH");
     const bool dma = (path_env && strcmp(path_env, "dma") == 0) || (p->flags & CRF_FLAG_ABSOLUTE_VALUE);
     if (dma && !c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), bytes));
-    if (!c->stream2) CRF_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        hipStream_t unused;
+        if (int r = second_stream(c, &unused)) return r;
+    }
     const bool two_streams = env_int_or("CRF_HOST_STREAMS", 2) == 2;
     const int fault_mode = env_int_or("CRF_HOST_FAULT", 2);           // 0 none, 1 touch, 2 MADV_POPULATE_WRITE
     const bool huge = env_int_or("CRF_HOST_HUGEPAGE", 1) == 1;        // ask for transparent huge pages first

@@ -104,6 +104,8 @@ int compute_device_ex(crf_context* c, const crf_params* p, const void* device_re
                       void* stream, const RefOverride* ref_override);
 int prepare_device_ex(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream,
                       const RefOverride* ref_override);
+// the context's second stream (created on first use)
+int second_stream(crf_context* c, hipStream_t* out);
 // the override that makes other contexts read the reference values of local point (x, y, z) out of `owner`'s members
 int reference_override(crf_context* owner, bool secondary, int x, int y, int z, RefOverride* out);
 // referenceValues[c] = (secondary ? secondary members : members)[c][IDXS(x,y,z)] into a device buffer, stream-ordered

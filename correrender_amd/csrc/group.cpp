@@ -8,13 +8,13 @@
 //   * every device has its own crf_context (members resident in ITS HBM, its own streams) and a persistent worker
 //     thread bound to it, so the launches of the N devices are issued concurrently, not one device after the other;
 //   * per evaluation there is ONE exchange: the cs values of the reference point live in the slab of one device (the
-//     owner).  With distinct ordinals the owner gathers them and they are broadcast -- RCCL (ncclBroadcast over xGMI, one
-//     persistent single-process communicator from ncclCommInitAll, one rank per worker thread).  When a device ordinal
-//     repeats (rehearsal of an N-slab group on fewer GPUs: RCCL refuses two ranks on one device) or CRF_GROUP_EXCHANGE=peer
-//     asks for it, the exchange is a DIRECT READ: every device's reference-side preparation kernel reads the cs values
-//     straight out of the owner's member volumes (peer access over xGMI) -- no copy, no event, no rendezvous between the
-//     workers; CRF_GROUP_EXCHANGE=copy (or a pair of devices without peer access) selects the staged form (owner
-//     gathers, the others hipMemcpyPeerAsync);
+//     owner).  Default, whenever every pair of devices has peer access (the xGMI-connected MI355X of a node; trivially
+//     when an ordinal repeats -- the rehearsal of an N-slab group on fewer GPUs): a DIRECT READ -- every device's
+//     reference-side preparation kernel reads the cs values straight out of the owner's member volumes -- no collective,
+//     no copy, no event, no rendezvous between the workers.  CRF_GROUP_EXCHANGE=rccl (and the default without peer
+//     access): the owner gathers and ncclBroadcast distributes (one persistent single-process communicator from
+//     ncclCommInitAll, one rank per worker thread; RCCL refuses two ranks on one device).  CRF_GROUP_EXCHANGE=copy: the
+//     staged form (owner gathers, the others hipMemcpyPeerAsync);
 //   * crf_group_compute_batch[_device] evaluates MANY reference points per hand-off: the reference vectors of up to 32
 //     points travel in one collective (owners fill their rows, one ncclAllReduce(sum)) or are read directly, the
 //     reference-side preparations of a block run first into prepared slots and its per-voxel kernels follow back to
@@ -94,8 +94,14 @@ thread_local std::string g_group_create_error;
 
 }  // namespace
 
+// per device slot: the events that order a batch's preparation stream against its main stream
+struct SlotEvents {
+    hipEvent_t prep_done[2] = {nullptr, nullptr}, block_done[2] = {nullptr, nullptr}, rows_ready = nullptr;
+};
+
 struct crf_group {
     int n = 0;
+    std::vector<SlotEvents> events;
     std::vector<int> ordinals;
     std::vector<crf_context*> ctx;
     std::vector<float*> d_refvec;        // per device: the cs reference values of the current evaluation
@@ -167,9 +173,12 @@ void crf_group_destroy(crf_group* g) {
         if (c && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(c);
     release_buffers(g);
     for (int r = 0; r < g->n; r++) {
-        if (g->ref_ready[size_t(r)]) {
-            (void)hipSetDevice(g->ordinals[size_t(r)]);
-            (void)hipEventDestroy(g->ref_ready[size_t(r)]);
+        (void)hipSetDevice(g->ordinals[size_t(r)]);
+        if (g->ref_ready[size_t(r)]) (void)hipEventDestroy(g->ref_ready[size_t(r)]);
+        if (size_t(r) < g->events.size()) {
+            SlotEvents& ev = g->events[size_t(r)];
+            for (hipEvent_t e : {ev.prep_done[0], ev.prep_done[1], ev.block_done[0], ev.block_done[1], ev.rows_ready})
+                if (e) (void)hipEventDestroy(e);
         }
         crf_destroy(g->ctx[size_t(r)]);
     }
@@ -189,6 +198,7 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
     g->ctx.assign(size_t(num_devices), nullptr);
     g->d_refvec.assign(size_t(num_devices), nullptr);
     g->d_rows.assign(size_t(num_devices), nullptr);
+    g->events.assign(size_t(num_devices), SlotEvents());
     g->ref_ready.assign(size_t(num_devices), nullptr);
     g->z_begin.assign(size_t(num_devices), 0);
     g->z_count.assign(size_t(num_devices), 0);
@@ -204,41 +214,29 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
         // the devices of a group share the host: bound each context's copier threads (host-output evaluations)
         g->ctx[size_t(r)]->copy_threads_cap = std::max(2, 16 / num_devices);
         (void)hipSetDevice(device_ordinals[r]);
-        if (hipEventCreateWithFlags(&g->ref_ready[size_t(r)], hipEventDisableTiming) != hipSuccess) {
+        SlotEvents& ev = g->events[size_t(r)];
+        bool events_ok = true;
+        for (hipEvent_t* e : {&ev.prep_done[0], &ev.prep_done[1], &ev.block_done[0], &ev.block_done[1], &ev.rows_ready})
+            events_ok = events_ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        if (!events_ok || hipEventCreateWithFlags(&g->ref_ready[size_t(r)], hipEventDisableTiming) != hipSuccess) {
             g_group_create_error = "crf_group_create: hipEventCreate failed";
             g->n = r + 1;
             crf_group_destroy(g);
             return CRF_ERR_DEVICE;
         }
     }
-    // the exchange: RCCL over xGMI when every slot has its own device
+    // The exchange.  CRF_GROUP_EXCHANGE = "peer" | "copy" | "rccl" forces a form; by default the reference vector is READ
+    // DIRECTLY out of the owner's member volumes when every pair of devices has peer access (all MI355X of a node do, over
+    // xGMI; trivially true when an ordinal repeats) -- no collective, no copy, no rendezvous between the workers --, else
+    // RCCL (ncclBroadcast / ncclAllReduce on a single-process communicator) when the ordinals are distinct, else staged
+    // peer copies.
     const bool distinct = std::set<int>(g->ordinals.begin(), g->ordinals.end()).size() == size_t(num_devices);
-    const char* forced = getenv("CRF_GROUP_EXCHANGE");  // "peer" (direct reads) | "copy" (staged peer copy) | "rccl"
-    const bool want_peer = forced && (strcmp(forced, "peer") == 0 || strcmp(forced, "copy") == 0);
-    if (num_devices == 1 && !(forced && strcmp(forced, "rccl") == 0)) {
-        g->exchange = "none (one device)";
-    } else if (distinct && !want_peer) {
-        if (!g->rccl.load()) {
-            g_group_create_error = "crf_group_create: " + g->rccl.error;
-            crf_group_destroy(g);
-            return CRF_ERR_DEVICE;
-        }
-        g->comms.assign(size_t(num_devices), nullptr);
-        const int rc = g->rccl.CommInitAll(g->comms.data(), num_devices, g->ordinals.data());
-        if (rc != 0) {
-            g_group_create_error = fmt("crf_group_create: ncclCommInitAll failed: %s",
-                                       g->rccl.GetErrorString ? g->rccl.GetErrorString(rc) : "?");
-            g->comms.clear();
-            crf_group_destroy(g);
-            return CRF_ERR_DEVICE;
-        }
-        g->exchange = "rccl (ncclBroadcast, single-process communicator)";
-    } else {
-        // peer exchange: let every device read its peers' memory where the fabric allows it.  When every pair can, the
-        // exchange is DIRECT: each device's reference-side preparation kernel reads the cs reference values straight
-        // out of the owner's member volumes (over xGMI, or locally when an ordinal repeats) -- no copy, no event, no
-        // rendezvous between the workers.  Otherwise the owner gathers and the others copy (staged, one rendezvous).
-        bool all_peers = true;
+    const char* forced = getenv("CRF_GROUP_EXCHANGE");
+    const bool want_rccl = forced && strcmp(forced, "rccl") == 0;
+    const bool want_copy = forced && strcmp(forced, "copy") == 0;
+    const bool want_peer = forced && strcmp(forced, "peer") == 0;
+    bool all_peers = true;
+    if (num_devices > 1 && !want_rccl) {
         for (int a = 0; a < num_devices; a++) {
             (void)hipSetDevice(g->ordinals[size_t(a)]);
             for (int b = 0; b < num_devices; b++) {
@@ -253,11 +251,33 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
             }
         }
         (void)hipGetLastError();
-        const bool want_copy = forced && strcmp(forced, "copy") == 0;
-        g->direct = all_peers && !want_copy;
-        const char* why = distinct ? "forced" : "a device ordinal repeats: rehearsal";
-        g->exchange = g->direct ? fmt("peer read (direct gather from the owner's members; %s)", why)
-                                : fmt("peer copy (staged: owner gathers, the others copy; %s)", why);
+    }
+    const char* why = forced ? "CRF_GROUP_EXCHANGE" : distinct ? "every pair of devices has peer access" : "a device ordinal repeats: rehearsal";
+    if (num_devices == 1 && !want_rccl) {
+        g->exchange = "none (one device)";
+    } else if (!want_rccl && !want_copy && all_peers) {
+        g->direct = true;
+        g->exchange = fmt("peer read (direct gather from the owner's members; %s)", why);
+    } else if (want_rccl || (distinct && !want_copy && !want_peer)) {
+        if (!g->rccl.load()) {
+            g_group_create_error = "crf_group_create: " + g->rccl.error;
+            crf_group_destroy(g);
+            return CRF_ERR_DEVICE;
+        }
+        g->comms.assign(size_t(num_devices), nullptr);
+        const int rc = g->rccl.CommInitAll(g->comms.data(), num_devices, g->ordinals.data());
+        if (rc != 0) {
+            g_group_create_error = fmt("crf_group_create: ncclCommInitAll failed: %s",
+                                       g->rccl.GetErrorString ? g->rccl.GetErrorString(rc) : "?");
+            g->comms.clear();
+            crf_group_destroy(g);
+            return CRF_ERR_DEVICE;
+        }
+        g->exchange = fmt("rccl (ncclBroadcast / ncclAllReduce, single-process communicator; %s)",
+                          forced ? "CRF_GROUP_EXCHANGE" : "no peer access between some pair of devices");
+    } else {
+        g->exchange = fmt("peer copy (staged: owner gathers, the others copy; %s)",
+                          forced ? "CRF_GROUP_EXCHANGE" : "no peer access between some pair of devices");
     }
     // one persistent worker per device slot, bound to its device once
     g->workers = std::make_unique<crf::SpinPool>(num_devices, [g](int r) { (void)hipSetDevice(g->ordinals[size_t(r)]); });
@@ -564,12 +584,30 @@ int group_compute(crf_group* g, const crf_params* params, int count, float* cons
                                               ov[size_t(j)]));
                 }
             } else if (rc == CRF_OK) {
-                // reference-side preparations of the block first (tiny kernels), then its per-voxel kernels back to back
-                const int slot0 = (b0 / kBatchRows) % 2 * kBatchRows;
-                for (int j = 0; j < bn && rc == CRF_OK; j++) {
+                // The reference-side preparations of the block (tiny kernels) run on the context's SECOND stream, one block
+                // ahead of the per-voxel kernels, which follow back to back on the main stream: the main stream carries
+                // nothing but per-voxel kernels.  Slots alternate between the two halves of the prepared-slot table;
+                // events order a half's re-use after the kernels that read it.
+                const int parity = (b0 / kBatchRows) % 2;
+                const int slot0 = parity * kBatchRows;
+                SlotEvents& ev = g->events[size_t(r)];
+                hipStream_t aux = nullptr;
+                note(crf::second_stream(c, &aux));
+                bool ok = rc == CRF_OK;
+                if (ok && b0 >= 2 * kBatchRows) ok = hipStreamWaitEvent(aux, ev.block_done[parity], 0) == hipSuccess;
+                bool has_rows = false;
+                for (int j = 0; j < bn; j++) has_rows = has_rows || dref[size_t(j)] != nullptr;
+                if (ok && has_rows)  // rows exchanged on the main stream (RCCL): the preparations read them
+                    ok = hipEventRecord(ev.rows_ready, c->stream) == hipSuccess && hipStreamWaitEvent(aux, ev.rows_ready, 0) == hipSuccess;
+                for (int j = 0; j < bn && ok && rc == CRF_OK; j++) {
                     crf_params local = local_params(b0 + j);
                     if (local.flags & CRF_FLAG_SYMMETRIC) continue;  // no reference side
-                    note(crf::prepare_device_ex(c, &local, dref[size_t(j)], slot0 + j, nullptr, ov[size_t(j)]));
+                    note(crf::prepare_device_ex(c, &local, dref[size_t(j)], slot0 + j, aux, ov[size_t(j)]));
+                }
+                if (ok) ok = hipEventRecord(ev.prep_done[parity], aux) == hipSuccess && hipStreamWaitEvent(c->stream, ev.prep_done[parity], 0) == hipSuccess;
+                if (!ok) {
+                    c->err = "ordering the preparation stream of a batch failed";
+                    note(CRF_ERR_DEVICE);
                 }
                 for (int j = 0; j < bn && rc == CRF_OK; j++) {
                     const int i = b0 + j;
@@ -577,6 +615,7 @@ int group_compute(crf_group* g, const crf_params* params, int count, float* cons
                     if (!(local.flags & CRF_FLAG_SYMMETRIC)) local.prepared_slot = slot0 + j + 1;
                     note(crf_compute_device(c, &local, nullptr, device_outs[size_t(i) * size_t(g->n) + size_t(r)], nullptr));
                 }
+                if (rc == CRF_OK && hipEventRecord(ev.block_done[parity], c->stream) != hipSuccess) note(CRF_ERR_DEVICE);
             }
             if (trace && r == 0)
                 fprintf(stderr, "crf_group slot 0: job started %.0f us after the call, exchange of block %d issued by %.0f us, "

@@ -196,10 +196,13 @@ int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* d
  * into z-slabs (the first zs % N slabs one slice longer -- with x-fastest volumes a slab of every member is contiguous
  * and the result slabs concatenate in the caller's buffer), each device keeps its slab of every member resident in its
  * own HBM and is driven by its own worker thread inside the library, and every evaluation has one exchange step: the
- * device whose slab holds the reference point gathers the cs reference values (CorrelationCalculator.cpp:802,815-817)
- * and broadcasts them -- ncclBroadcast on a persistent single-process RCCL communicator over xGMI when the ordinals
- * are distinct; when an ordinal repeats (a rehearsal of N slabs on fewer GPUs) or the environment says
- * CRF_GROUP_EXCHANGE=peer, every device reads the cs values directly out of the owner's member volumes (peer access).  Each device then evaluates its slab and copies it straight into its part
+ * device whose slab holds the reference point (the owner) has the cs reference values
+ * (CorrelationCalculator.cpp:802,815-817).  By default every other device READS them directly out of the owner's member
+ * volumes -- peer access over xGMI, fused into its reference-side preparation kernel: no collective, no copy, no
+ * rendezvous.  CRF_GROUP_EXCHANGE=rccl (and the default when some pair of devices lacks peer access): the owner gathers
+ * and ncclBroadcast distributes them on a persistent single-process RCCL communicator.  CRF_GROUP_EXCHANGE=copy: staged
+ * peer copies.  crf_group_exchange() names the form in use.  Each device then evaluates its slab and copies it straight
+ * into its part
  * of the caller's buffer (the copies of the N devices run concurrently).  Results are bit-identical to a single
  * context's.  Same conventions as above: one caller thread, status codes, crf_group_last_error. */
 typedef struct crf_group crf_group;
@@ -207,7 +210,7 @@ int crf_group_create(const int* device_ordinals, int num_devices, crf_group** ou
 void crf_group_destroy(crf_group* group);
 const char* crf_group_last_error(const crf_group* group);   /* group == NULL: last failed crf_group_create of this thread */
 int crf_group_size(const crf_group* group);
-/* "rccl (...)", "peer copy (...)" or "none (one device)": how the reference vector travels. */
+/* "peer read (...)", "rccl (...)", "peer copy (...)" or "none (one device)": how the reference vector travels. */
 const char* crf_group_exchange(const crf_group* group);
 /* The context that drives device slot `slot` (its LOCAL grid is the slab): for per-device helpers such as
  * crf_bind_members_device or crf_last_kernel_name.  Owned by the group. */
