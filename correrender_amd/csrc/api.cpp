@@ -91,6 +91,7 @@ int install_member_table(crf_context* c) {
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     c->minmax_valid = false;
     c->host_chunks = 0;  // the per-range pointer tables of the host-output path describe the old members
+    c->windows = 0;      // ... and so do the window tables of a >= 4 GiB grid
     return CRF_OK;
 }
 
@@ -253,10 +254,6 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     if (xs <= 0 || ys <= 0 || zs <= 0 || cs <= 0)
         return fail(c, CRF_ERR_ARGUMENT, fmt("invalid grid %dx%dx%d with %d members", xs, ys, zs, cs));
     const size_t n = size_t(xs) * size_t(ys) * size_t(zs);
-    // 32-bit byte offsets inside a member, and the kernels' out-of-range sentinel offset (crf_device.h
-    // kOutOfRangeOffset = 0xFFFFFFF0) must lie beyond the end of every member
-    if (n * sizeof(float) >= size_t(0xFFFFFFF0u))
-        return fail(c, CRF_ERR_UNSUPPORTED, "a member volume (or z-slab) of 4 GiB or more is not supported; shard it");
     if (int r = bind_device(c)) return r;
     CRF_HIP(c, hipDeviceSynchronize());  // evaluations the caller left in flight on its own streams still read the scratch
     release_members(c);
@@ -288,6 +285,14 @@ int crf_set_grid(crf_context* c, int xs, int ys, int zs, int cs) {
     c->cs = cs;
     c->num_voxels = n;
     c->alloc_voxels = n;
+    // The kernels address a member with 32-bit byte offsets, and their out-of-range sentinel offset (crf_device.h
+    // kOutOfRangeOffset = 0xFFFFFFF0) must lie beyond the end of every member: a member volume of 4 GiB or more (1024^3 is
+    // exactly 4 GiB; the reference has no limit) is evaluated in WINDOWS of kWindowVoxels voxels, one launch each, through
+    // member-pointer tables advanced by the window's first voxel (ensure_windows below).
+    c->windowed = n * sizeof(float) >= size_t(0xFFFFFFF0u);
+    if (c->d_window_tables) (void)hipFree(c->d_window_tables);
+    c->d_window_tables = nullptr;
+    c->windows = 0;
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_member_table), sizeof(float*) * size_t(cs)));
     CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_ref), sizeof(float) * size_t(cs)));
     const std::vector<double> tables = build_tables(cs);
@@ -388,6 +393,7 @@ static int install_secondary_table(crf_context* c) {
                               hipMemcpyHostToDevice, c->stream));
     CRF_HIP(c, hipStreamSynchronize(c->stream));
     c->sec_minmax_valid = false;
+    c->windows = 0;
     return CRF_OK;
 }
 
@@ -452,6 +458,66 @@ static int ensure_workspace(crf_context* c, size_t need) {
     }
     return CRF_OK;
 }
+
+}  // extern "C"
+
+// ---- member volumes of 4 GiB and more: evaluation in windows ----------------------------------------------------------
+constexpr size_t kWindowVoxels = size_t(1) << 29;  // 2 GiB of every member per launch
+
+static int ensure_windows(crf_context* c) {
+    if (c->windows > 0) return CRF_OK;
+    const int windows = int((c->alloc_voxels + kWindowVoxels - 1) / kWindowVoxels);
+    const bool sec = !c->sec_members.empty();
+    std::vector<const float*> table(size_t(windows) * size_t(c->cs) * (sec ? 2 : 1));
+    for (int w = 0; w < windows; w++)
+        for (int m = 0; m < c->cs; m++) {
+            table[(size_t(w) * (sec ? 2 : 1)) * size_t(c->cs) + size_t(m)] = c->members[size_t(m)] + size_t(w) * kWindowVoxels;
+            if (sec) table[(size_t(w) * 2 + 1) * size_t(c->cs) + size_t(m)] = c->sec_members[size_t(m)] + size_t(w) * kWindowVoxels;
+        }
+    if (c->d_window_tables) (void)hipFree(c->d_window_tables);
+    c->d_window_tables = nullptr;
+    CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_window_tables), table.size() * sizeof(float*)));
+    CRF_HIP(c, hipMemcpy(c->d_window_tables, table.data(), table.size() * sizeof(float*), hipMemcpyHostToDevice));
+    c->windows = windows;
+    c->window_has_secondary = sec;
+    return CRF_OK;
+}
+
+// narrows the context to one window for the duration of a launch; restores it on every exit path
+struct WindowScope {
+    crf_context* c;
+    const float** table;
+    const float** sec_table;
+    size_t voxels;
+    explicit WindowScope(crf_context* ctx) : c(ctx), table(ctx->d_member_table), sec_table(ctx->d_sec_table), voxels(ctx->num_voxels) {}
+    size_t select(int w) {  // returns the window's first voxel
+        const size_t per = size_t(c->window_has_secondary ? 2 : 1) * size_t(c->cs);
+        c->d_member_table = c->d_window_tables + size_t(w) * per;
+        if (c->window_has_secondary) c->d_sec_table = c->d_window_tables + size_t(w) * per + size_t(c->cs);
+        c->num_voxels = std::min(kWindowVoxels, c->alloc_voxels - size_t(w) * kWindowVoxels);
+        return size_t(w) * kWindowVoxels;
+    }
+    ~WindowScope() {
+        c->d_member_table = table;
+        c->d_sec_table = sec_table;
+        c->num_voxels = voxels;
+    }
+};
+
+// runs launch(out + first voxel of the window) for every window of a >= 4 GiB grid, or once for an ordinary grid
+template <class Launch>
+static int for_each_window(crf_context* c, float* out, Launch&& launch) {
+    if (!c->windowed) return launch(out);
+    if (int r = ensure_windows(c)) return r;
+    WindowScope scope(c);
+    for (int w = 0; w < c->windows; w++) {
+        const size_t first = scope.select(w);
+        if (int r = launch(out + first)) return r;
+    }
+    return CRF_OK;
+}
+
+extern "C" {
 
 // CRF_FLAG_SYMMETRIC: measure(primary members at v, secondary members at v) for every voxel v
 static int compute_symmetric(crf_context* c, const crf_params* p, float* out, hipStream_t s) {
@@ -649,8 +715,26 @@ static int copy_result_to_host(crf_context* c, const float* d_src, float* host_o
 
 // phase: bit 0 = reference-side preparation, bit 1 = per-voxel kernel (crf_internal.h RefSource::phase);
 // slot < 0: the context's own preparation buffer
+static int compute_impl_one(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                            void* stream, unsigned phase, int slot, const crf::RefOverride* ov);
+
+// An ordinary grid: one call.  A grid whose members are 4 GiB or larger: the reference side once, from the whole grid
+// (the reference point indexes it with 64 bits), then the per-voxel kernel window by window.
 static int compute_impl(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
                         void* stream, unsigned phase, int slot, const crf::RefOverride* ov = nullptr) {
+    if (!c || !c->windowed || !p || (p->flags & CRF_FLAG_SYMMETRIC))
+        return compute_impl_one(c, p, device_reference_values, device_out, stream, phase, slot, ov);
+    if (phase & 1u)
+        if (int r = compute_impl_one(c, p, device_reference_values, nullptr, stream, 1u, slot, ov)) return r;
+    if (!(phase & 2u)) return CRF_OK;
+    if (!device_out) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    return for_each_window(c, static_cast<float*>(device_out), [&](float* o) {
+        return compute_impl_one(c, p, nullptr, o, stream, 2u, slot, nullptr);
+    });
+}
+
+static int compute_impl_one(crf_context* c, const crf_params* p, const void* device_reference_values, void* device_out,
+                            void* stream, unsigned phase, int slot, const crf::RefOverride* ov) {
     if (int r = check_ready(c)) return r;
     if (!p || (!device_out && (phase & 2u))) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (p->measure < CRF_PEARSON || p->measure > CRF_KMI_CC)
@@ -662,7 +746,7 @@ static int compute_impl(crf_context* c, const crf_params* p, const void* device_
     float* out = static_cast<float*>(device_out);
     if (p->flags & CRF_FLAG_SYMMETRIC) {
         if (phase != 3u) return fail(c, CRF_ERR_ARGUMENT, "the symmetric mode has no reference-side preparation");
-        return compute_symmetric(c, p, out, s);
+        return for_each_window(c, out, [&](float* o) { return compute_symmetric(c, p, o, s); });
     }
     float* prep = c->d_prep;
     if (slot >= 0) {
@@ -963,7 +1047,7 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
     if (int r = bind_device(c)) return r;
     const size_t bytes = c->alloc_voxels * sizeof(float);
     const bool ranged = !(p->flags & CRF_FLAG_SYMMETRIC) && p->prepared_slot == 0 && bytes >= (size_t(8) << 20) &&
-                        env_int_or("CRF_PLAIN_D2H", 0) != 1;
+                        !c->windowed && env_int_or("CRF_PLAIN_D2H", 0) != 1;
     if (!ranged) {
         if (!c->d_out) CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_out), bytes));
         if (int r = compute_device_ex(c, p, device_reference_values, c->d_out, nullptr, ov)) return r;
@@ -1090,6 +1174,8 @@ int crf_compute_requests_device(crf_context* c, const crf_params* p, const void*
         if (v != 0) return fail(c, CRF_ERR_ARGUMENT, "crf_params.reserved must be zero");
     if (c->cs > crf::kMaxGenericMembers)
         return fail(c, CRF_ERR_UNSUPPORTED, fmt("pair requests support at most %d members", crf::kMaxGenericMembers));
+    if (c->windowed)
+        return fail(c, CRF_ERR_UNSUPPORTED, "pair requests address voxels with 32-bit byte offsets: member volumes of 4 GiB or more are not supported in request mode");
     if ((p->measure == CRF_MI_BINNED || p->measure == CRF_BINNED_MI_CC) && (p->num_bins < 1 || p->num_bins > 255))
         return fail(c, CRF_ERR_ARGUMENT, fmt("num_bins %d outside [1,255]", p->num_bins));
     if ((p->measure == CRF_MI_KRASKOV || p->measure == CRF_KMI_CC) && p->k < 1)
@@ -1178,8 +1264,11 @@ int crf_compute_ensemble_stat_device(crf_context* c, int stat, void* device_out,
         e1 = take_event(c);
     }
     crf::LaunchInfo info;
-    hipError_t e = crf::launch_ensemble_stat(stat, c->d_member_table, c->cs, c->num_voxels,
-                                             static_cast<float*>(device_out), s, e0, e1, &info);
+    hipError_t e = hipSuccess;
+    (void)for_each_window(c, static_cast<float*>(device_out), [&](float* o) {
+        if (e == hipSuccess) e = crf::launch_ensemble_stat(stat, c->d_member_table, c->cs, c->num_voxels, o, s, e0, e1, &info);
+        return CRF_OK;
+    });
     c->last_kernel = info.kernel_name ? info.kernel_name : "";
     if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
@@ -1209,8 +1298,13 @@ int crf_compute_set_predicate_device(crf_context* c, int op, float comparison_va
         e1 = take_event(c);
     }
     crf::LaunchInfo info;
-    hipError_t e = crf::launch_set_predicate(c->d_member_table, c->cs, c->num_voxels, op, comparison_value, count_lower,
-                                             count_upper, static_cast<float*>(device_out), s, e0, e1, &info);
+    hipError_t e = hipSuccess;
+    (void)for_each_window(c, static_cast<float*>(device_out), [&](float* o) {
+        if (e == hipSuccess)
+            e = crf::launch_set_predicate(c->d_member_table, c->cs, c->num_voxels, op, comparison_value, count_lower, count_upper,
+                                          o, s, e0, e1, &info);
+        return CRF_OK;
+    });
     c->last_kernel = info.kernel_name ? info.kernel_name : "";
     if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
@@ -1241,7 +1335,7 @@ int crf_compute_dkl_device(crf_context* c, int estimator, int num_bins, int k, v
         return fail(c, CRF_ERR_ARGUMENT, fmt("k=%d must be in [1, cs-1=%d]", k, c->cs - 1));
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    if (int r = ensure_workspace(c, crf::dkl_workspace_bytes(c->cs, estimator, num_bins, c->num_voxels))) return r;
+    if (int r = ensure_workspace(c, crf::dkl_workspace_bytes(c->cs, estimator, num_bins, std::min(c->num_voxels, kWindowVoxels)))) return r;
     // psi(n) = -gamma + H_{n-1} (boost::math::digamma at positive integers, DKL.cpp:156)
     const double knn_const =
         estimator == CRF_DKL_ENTROPY_KNN && c->cs > 1 ? psi_int(c->cs) - psi_int(k) + std::log(2.0) : 0.0;
@@ -1251,8 +1345,13 @@ int crf_compute_dkl_device(crf_context* c, int estimator, int num_bins, int k, v
         e1 = take_event(c);
     }
     crf::LaunchInfo info;
-    hipError_t e = crf::launch_dkl(c->d_member_table, c->cs, c->num_voxels, estimator, num_bins, k, knn_const,
-                                   c->d_workspace, static_cast<float*>(device_out), s, e0, e1, &info);
+    hipError_t e = hipSuccess;
+    (void)for_each_window(c, static_cast<float*>(device_out), [&](float* o) {
+        if (e == hipSuccess)
+            e = crf::launch_dkl(c->d_member_table, c->cs, c->num_voxels, estimator, num_bins, k, knn_const, c->d_workspace, o, s,
+                                e0, e1, &info);
+        return CRF_OK;
+    });
     c->last_kernel = info.kernel_name ? info.kernel_name : "";
     if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
     if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));
@@ -1281,6 +1380,7 @@ size_t crf_tiled_element_count(int xs, int ys, int zs) {
 int crf_tile_field_device(crf_context* c, const void* device_linear, void* device_tiled, void* stream) {
     if (!c) return CRF_ERR_ARGUMENT;
     if (c->cs <= 0) return fail(c, CRF_ERR_STATE, "crf_set_grid has not been called");
+    if (c->windowed) return fail(c, CRF_ERR_UNSUPPORTED, "re-tiling a field of 4 GiB or more is not supported");
     if (!device_linear || !device_tiled) return fail(c, CRF_ERR_ARGUMENT, "null argument");
     if (int r = bind_device(c)) return r;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;

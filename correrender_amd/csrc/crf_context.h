@@ -70,6 +70,11 @@ struct crf_context {
     std::unique_ptr<crf::SpinPool> copy_pool;      // copier threads, lazily
     int copy_threads = 0;                          // how many of them a copy uses (calibrated at first use)
     int copy_threads_cap = 0;                      // > 0: upper bound set by the owner (a device group shares the host)
+    // member volumes of 4 GiB or more: evaluated in windows (api.cpp: ensure_windows)
+    bool windowed = false;
+    const float** d_window_tables = nullptr;  // windows x (1 or 2) x cs pointers (primary [, secondary] members)
+    int windows = 0;                          // 0: tables not built for the current members
+    bool window_has_secondary = false;
     size_t alloc_voxels = 0;  // voxels of the whole local grid (num_voxels is narrowed while a chunk is being launched)
 };
 

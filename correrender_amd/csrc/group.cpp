@@ -436,6 +436,10 @@ int exchange_one(crf_group* g, int r, const crf_params* p, const RefPlan& plan) 
     if (r == plan.owner && rc == CRF_OK && hipEventRecord(g->ref_ready[size_t(r)], c->stream) != hipSuccess) rc = CRF_ERR_DEVICE;
     g->workers->barrier();  // the owner's event is recorded: the others may wait on it
     if (r != plan.owner) {
+        // hipMemcpyPeerAsync is NOT reliably ordered behind kernels launched earlier on the same stream (measured with two
+        // slots on one device: in a batch the copy of evaluation i + 1 overtook the preparation kernel of evaluation i,
+        // which then read the next vector -- tools/repro_group_batch.py): drain the stream before the copy is issued.
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == CRF_OK) rc = CRF_ERR_DEVICE;
         if (hipStreamWaitEvent(c->stream, g->ref_ready[size_t(plan.owner)], 0) != hipSuccess ||
             hipMemcpyPeerAsync(mine, g->ordinals[size_t(r)], g->d_refvec[size_t(plan.owner)], g->ordinals[size_t(plan.owner)],
                                sizeof(float) * size_t(g->cs), c->stream) != hipSuccess) {
@@ -443,7 +447,10 @@ int exchange_one(crf_group* g, int r, const crf_params* p, const RefPlan& plan) 
             if (rc == CRF_OK) rc = CRF_ERR_DEVICE;
         }
     }
-    // the owner must not overwrite its vector (next evaluation's gather) before the others have enqueued their copies
+    // The owner must not overwrite its vector (the next evaluation's gather, possibly within the same batch job) before
+    // the others' copies have EXECUTED, not just been enqueued: every copier waits for its copy before the rendezvous.
+    // (The staged form is the fallback for devices without peer access; the direct form has no such step.)
+    if (r != plan.owner && hipStreamSynchronize(c->stream) != hipSuccess && rc == CRF_OK) rc = CRF_ERR_DEVICE;
     g->workers->barrier();
     return rc;
 }
