@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--cpu-slices", type=int, default=0, help="z-slices of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--cpu-baseline-child", default="", help=argparse.SUPPRESS)  # internal: see cpu_baseline_bound()
     return ap.parse_args()
 
 
@@ -107,6 +108,8 @@ def summarize(ms_blocks):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:  # a child of cpu_baseline_bound(): CPU only, never touches the GPU
+        return cpu_baseline_child(args.cpu_baseline_child)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the first HIP call of this process
@@ -424,7 +427,65 @@ def cpu_baseline(args, eng, members, out, measure, last_pt, kwargs):
                      f"median of {len(times)} runs, OpenMP over voxels (static schedule, {threads} threads)"}
     parity = {"checked_voxels": int(n), "bit_identical": int(same.sum()), "max_abs_err": max_abs,
               "against": cpu["kind"]}
+    # the same sample once more with the threads bound to cores and the input pages placed by the threads that read them
+    # (a two-socket host under-states the reference otherwise): a child process, because libgomp reads OMP_PROC_BIND /
+    # OMP_PLACES when it is loaded
+    try:
+        cpu["bound"] = cpu_baseline_bound(sample, ref_values, m, use_ref, okw if not use_ref else {})
+    except Exception as e:  # the bound variant is an extra: never fail the bench line over it
+        cpu["bound"] = {"error": str(e)[:200]}
+    cpu["first_touch"] = "one thread (the sample is copied from the GPU by the main thread)"
     return cpu, parity
+
+
+def cpu_baseline_bound(sample, ref_values, m, use_ref, okw):
+    import numpy as np
+    shm = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path("/tmp")
+    path = shm / f"crf_cpu_sample_{os.getpid()}.npz"
+    try:
+        np.savez(path, sample=sample, ref_values=ref_values, m=m, use_ref=use_ref,
+                 okw=json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in okw.items()}))
+        env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-child", str(path)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"child failed (rc {r.returncode}): {r.stderr[-300:]}")
+        return json.loads(lines[-1])
+    finally:
+        path.unlink(missing_ok=True)
+
+
+def cpu_baseline_child(path):
+    """OMP_PROC_BIND / OMP_PLACES are set in this process's environment: first-touch the sample with the OpenMP threads
+    (same static partition over voxels as the timed loop), then time the CPU calculator on it like the parent did."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    d = np.load(path, allow_pickle=False)
+    m, use_ref = int(d["m"]), bool(d["use_ref"])
+    okw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.loads(str(d["okw"])).items()}
+    oracle = oracle_lib.load_oracle()
+    sample = oracle.first_touch_copy(d["sample"])
+    ref_values = np.array(d["ref_values"], np.float32)
+    if use_ref:
+        ref = oracle_lib.load_reference()
+        run = lambda: ref.field(m, sample, ref_values)
+    else:
+        run = lambda: oracle.field(m, sample, ref_values, **okw)
+    run()
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_all < 10.0 and len(times) < 15):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    print(json.dumps({"value": round(sample[0].size / med / 1e6, 2), "unit": "Mvoxel-corr/s", "threads_used": oracle.max_threads(),
+                      "omp_proc_bind": os.environ.get("OMP_PROC_BIND", "unset"), "omp_places": os.environ.get("OMP_PLACES", "unset"),
+                      "first_touch": "by the OpenMP threads, static partition over voxels (oracle_first_touch_copy)",
+                      "runs": len(times)}))
+    return 0
 
 
 def measure_host_boundary(args, eng, measure, pts, kwargs, n_total):

@@ -42,16 +42,9 @@ constexpr int kDxtMaxMembers = 128;
 __host__ __device__ inline int dxt_offset(int cs) { return (2 * cs + 7) / 8 * 8; }  // in doubles
 static_assert(size_t(((2 * kDxtMaxMembers + 7) / 8 * 8) + 128 * 128) * sizeof(double) <= kPrepBytes - 16, "prep buffer");
 
-// neighbours != 0 (kraskov_direct_kernel<..., PRUNE>): the table region holds, instead of the distance table, every point's
-// OTHER points in ascending order of x distance -- nbr_dx[i][s] = |px_i - px_j| of the s-th nearest j in x (ties by j),
-// rows of round_up(cs, 8) doubles padded with +inf, followed by the candidates' member indices nbr_j[i][s] as bytes
-// (rows of the same length, pads 0).  Voxel independent like the table: cs * round_up(cs, 8) * 9 bytes <= 147 KB.
-__host__ __device__ inline int nbr_width(int cs) { return (cs + 7) / 8 * 8; }
-static_assert(size_t(((2 * kDxtMaxMembers + 7) / 8 * 8)) * sizeof(double) + size_t(128) * 128 * 9 <= kPrepBytes - 16, "prep buffer");
-
 __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const float* const* __restrict__ members,
                                                            int cs, const double* __restrict__ noise_ref,
-                                                           double* __restrict__ prep, int neighbours) {
+                                                           double* __restrict__ prep) {
     extern __shared__ double px[];  // cs doubles
     for (int e = threadIdx.x; e < cs; e += blockDim.x) px[e] = double(load_ref(src, members, e)) + noise_ref[e];
     __syncthreads();
@@ -66,31 +59,7 @@ __global__ __launch_bounds__(256) void kraskov_prep_kernel(RefSource src, const 
     // point i, laid out [round_up(cs, 16)][round_up(cs, 8)] behind the two vectors (64-byte aligned).  The diagonal holds
     // the largest finite double (a point is not its own neighbour) and the rows of candidates past the end +inf, so the
     // kernel needs neither a self test nor an end test per pair; it reads a row segment of 8 with one scalar load.
-    if (cs <= kDxtMaxMembers && neighbours) {
-        double* nbr_dx = prep + dxt_offset(cs);
-        const int w = nbr_width(cs);
-        unsigned char* nbr_j = reinterpret_cast<unsigned char*>(nbr_dx + size_t(cs) * size_t(w));
-        for (int i = threadIdx.x; i < cs; i += blockDim.x) {
-            // rank of candidate j among the others: #{ j' : (|dx_j'|, j') < (|dx_j|, j) }, j' != i
-            const double xi = px[i];
-            for (int j = 0; j < cs; j++) {
-                if (j == i) continue;
-                const double dj = fabs(xi - px[j]);
-                int rank = 0;
-                for (int q = 0; q < cs; q++) {
-                    if (q == i) continue;
-                    const double dq = fabs(xi - px[q]);
-                    rank += (dq < dj || (dq == dj && q < j)) ? 1 : 0;
-                }
-                nbr_dx[size_t(i) * w + rank] = dj;
-                nbr_j[size_t(i) * w + rank] = (unsigned char)j;
-            }
-            for (int sidx = cs - 1; sidx < w; sidx++) {
-                nbr_dx[size_t(i) * w + sidx] = __longlong_as_double(0x7FF0000000000000ll);
-                nbr_j[size_t(i) * w + sidx] = 0;
-            }
-        }
-    } else if (cs <= kDxtMaxMembers) {
+    if (cs <= kDxtMaxMembers) {
         double* table = prep + dxt_offset(cs);
         const int rows = (cs + 15) / 16 * 16, cols = (cs + 7) / 8 * 8;
         for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) {
@@ -386,11 +355,7 @@ constexpr int direct_min_waves(int K, int TI, bool SYM) {
     return K <= 2 ? 4 : (K == 3 ? 3 : (K == 4 ? 2 : (K <= 32 ? 3 : 1)));
 }
 
-// PRUNE (cs <= 128, K = k <= 4, not SYM): sweep A visits a point's candidates in ascending order of their x distance (the
-// neighbour lists of kraskov_prep_kernel, scalar loads) and stops once the next x distance is no smaller than the K-th
-// best Chebyshev distance in EVERY lane: d = max(|dx|, |dy|) >= |dx|, so no later candidate can lower any of the K
-// smallest distances -- the multiset of the K smallest values, and with it the result, is that of the full sweep.
-template <int K, int TI, bool SYM = false, bool DXT = false, bool PRUNE = false>
+template <int K, int TI, bool SYM = false, bool DXT = false>
 __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_direct_kernel(const float* const* __restrict__ members,
                                                             const float* const* __restrict__ members_x,
                                                             const double* __restrict__ prep_px,
@@ -471,66 +436,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                 for (int q = 0; q < K; q++) best[t][q] = inf;
             }
             // ---- sweep A: the K smallest Chebyshev distances to OTHER points (MutualInformation.cpp:430-434)
-            if constexpr (PRUNE) {
-                constexpr int SB = 4;  // candidates per point and step: one s_load_dwordx8 of x distances, one dword of indices
-                const int w = nbr_width(cs);
-                const double* __restrict__ nbr_dx = prep_px + dxt_offset(cs);
-                const unsigned char* __restrict__ nbr_j = reinterpret_cast<const unsigned char*>(nbr_dx + size_t(cs) * size_t(w));
-                // Two step buffers: the loads of step s + 1 (list entries through the scalar cache, then the candidates'
-                // values) are issued before the pairs of step s are evaluated -- a step is a chain of three dependent
-                // loads (index -> member pointer -> value), far longer than its 16 pairs of arithmetic.
-                float yv[2][TI][SB];
-                double dxv[2][TI][SB];
-                int jv[2][TI][SB];
-                auto fetch = [&](auto buf, int s0) {
-                    constexpr int B = decltype(buf)::value;
-#pragma unroll
-                    for (int t = 0; t < TI; t++) {
-                        const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
-                        const uint32_t packed = *reinterpret_cast<const uint32_t*>(nbr_j + size_t(ii) * size_t(w) + s0);
-                        const double* dx_row = nbr_dx + size_t(ii) * size_t(w) + s0;
-#pragma unroll
-                        for (int u = 0; u < SB; u++) {
-                            jv[B][t][u] = int((packed >> (8 * u)) & 255u);
-                            dxv[B][t][u] = dx_row[u];
-                            yv[B][t][u] = load_member_cached(members[jv[B][t][u]], bytes, off);
-                        }
-                    }
-                };
-                // returns true when every point's K-th best distance is no larger than the x distance of the candidates
-                // still to come, in every lane (K == kk here)
-                auto evaluate = [&](auto buf) -> bool {
-                    constexpr int B = decltype(buf)::value;
-                    bool settled = true;
-#pragma unroll
-                    for (int t = 0; t < TI; t++) {
-#pragma unroll
-                        for (int u = 0; u < SB; u++) {
-                            const double pyj = double(yv[B][t][u]) + s_nq[jv[B][t][u]];
-                            double d = chebyshev_f64_sx(pyi[t] - pyj, dxv[B][t][u]);
-#pragma unroll
-                            for (int q = 0; q < K; q++) {
-                                const double lo = min_f64(best[t][q], d);
-                                if (q + 1 < K) d = max_f64(best[t][q], d);
-                                best[t][q] = lo;
-                            }
-                        }
-                        settled = settled && (dxv[B][t][SB - 1] >= best[t][K - 1]);
-                    }
-                    return __builtin_amdgcn_ballot_w64(!settled) == 0;
-                };
-                using B0 = std::integral_constant<int, 0>;
-                using B1 = std::integral_constant<int, 1>;
-                fetch(B0{}, 0);
-#pragma unroll 1
-                for (int s0 = 0; s0 < cs - 1; s0 += 2 * SB) {
-                    const bool more1 = s0 + SB < cs - 1;
-                    if (more1) fetch(B1{}, s0 + SB);
-                    if (evaluate(B0{}) || !more1) break;
-                    if (s0 + 2 * SB < cs - 1) fetch(B0{}, s0 + 2 * SB);
-                    if (evaluate(B1{})) break;
-                }
-            } else {
+            //      (the member values come in batches of JB loads issued back to back: one memory latency per batch)
 #pragma unroll 1
             for (int j0 = 0; j0 < cs; j0 += JB) {
                 float yb[JB], xb[SYM ? JB : 1];
@@ -544,8 +450,9 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                 // v_max_f64 would fall back to the finite x distance).  The point itself is masked by overwriting the
                 // HIGH dword of its distance with 0x7FEFFFFF -- a finite value beyond any real distance, whatever the
                 // low dword holds: one v_cndmask per pair instead of the two of a 64-bit select.
-#pragma unroll
-                for (int u = 0; u < JB; u++) {
+                // the second half of a batch is skipped when the batch ends within its first half (a wave-uniform branch:
+                // 56 members sweep 56 candidate slots, not 64)
+                auto candidate_a = [&](int u) {
                     const int j = j0 + u;
                     const int jc = j < cs ? j : cs - 1;
                     const double pxj = j < cs ? (SYM ? double(xb[SYM ? u : 0]) + s_px[jc] : s_px[jc]) : inf;
@@ -573,9 +480,14 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                             best[t][q] = lo;
                         }
                     }
+                };
+#pragma unroll
+                for (int u = 0; u < JB / 2; u++) candidate_a(u);
+                if (j0 + JB / 2 < cs) {
+#pragma unroll
+                    for (int u = JB / 2; u < JB; u++) candidate_a(u);
                 }
             }
-            }  // !PRUNE
 #pragma unroll
             for (int t = 0; t < TI; t++) {
                 double sel = best[t][0];
@@ -634,8 +546,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                     yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                     if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                 }
-#pragma unroll
-                for (int u = 0; u < JB; u++) {
+                auto candidate_c = [&](int u) {
                     const int jc = j0 + u < cs ? j0 + u : cs - 1;
                     // a candidate past the end is +inf: inside no [lo, hi) (hi is finite unless the voxel holds an
                     // infinity, and then the result is NaN or decided by the NaN flag anyway -- see below)
@@ -647,6 +558,12 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
 #pragma unroll
                         for (int t = 0; t < TI; t++) cx[t] += (pxj >= lox[t] && pxj < hix[t]) ? 1 : 0;
                     }
+                };
+#pragma unroll
+                for (int u = 0; u < JB / 2; u++) candidate_c(u);
+                if (j0 + JB / 2 < cs) {
+#pragma unroll
+                    for (int u = JB / 2; u < JB; u++) candidate_c(u);
                 }
             }
 #pragma unroll
@@ -947,12 +864,7 @@ static int direct_share_tiles() {
 void launch_kraskov_prep(const RefSource& ref, const float* const* d_members, int cs, const double* noise_ref,
                          double* d_prep, hipStream_t s) {
     hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(double), s, ref, d_members, cs,
-                       noise_ref, d_prep, 0);
-}
-static void launch_kraskov_prep_neighbours(const RefSource& ref, const float* const* d_members, int cs,
-                                           const double* noise_ref, double* d_prep, hipStream_t s) {
-    hipLaunchKernelGGL(kraskov_prep_kernel, dim3(1), dim3(256), size_t(cs) * sizeof(double), s, ref, d_members, cs,
-                       noise_ref, d_prep, 1);
+                       noise_ref, d_prep);
 }
 
 // O(cs) histogram kernel for any member count; hipErrorNotSupported when num_bins is too large for its LDS rows
@@ -967,14 +879,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     const double* noise_ref = d_tables + 2 * (cs + 1);
     const double* noise_query = noise_ref + cs;
     double* prep = reinterpret_cast<double*>(d_prep);
-    // x-ordered candidate sweeps with an early exit (PRUNE): 16..128 members, k <= 4
-    const char* prune_env = getenv("CRF_KRASKOV_PRUNE");  // tuning: 0 = never, 1 = wherever it exists
-    const bool prune = cs >= 16 && cs <= kDxtMaxMembers && kk >= 1 && kk <= 4 && a.k == kk &&
-                       (prune_env ? *prune_env == '1' : false);
-    if (ref.prepare()) {
-        if (prune) launch_kraskov_prep_neighbours(ref, d_members, cs, noise_ref, prep, s);
-        else launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
-    }
+    if (ref.prepare()) launch_kraskov_prep(ref, d_members, cs, noise_ref, prep, s);
     if (!ref.run()) return hipGetLastError();
     const size_t tiles = (num_voxels + 63) / 64;
     const size_t groups = (tiles + 3) / 4;
@@ -1012,28 +917,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     const bool ti4_k4 = ti4_env ? *ti4_env == '1' : true;
     const bool ti4_k3_plain = ti4_env && *ti4_env == '1';
     const bool ti4 = ti4_table;
-    const char* prune_ti = getenv("CRF_KRASKOV_PRUNE_TI");  // tuning: points per sweep of the pruned kernel (1, 2, 4)
-    const int pti = prune_ti ? atoi(prune_ti) : 4;
-#define CRF_LAUNCH_PRUNED(K, TI)                                                                                         \
-    hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, false, false, true>), dim3(blocks), dim3(256), lds, s, d_members,   \
-                       nullptr, prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, 1)
-#define CRF_LAUNCH_PRUNED_K(K)                    \
-    if (pti == 1) {                               \
-        CRF_LAUNCH_PRUNED(K, 1);                  \
-    } else if (pti == 2) {                        \
-        CRF_LAUNCH_PRUNED(K, 2);                  \
-    } else {                                      \
-        CRF_LAUNCH_PRUNED(K, 4);                  \
-    }
-    if (prune) {
-        switch (kk) {
-            case 1: CRF_LAUNCH_PRUNED_K(1) break;
-            case 2: CRF_LAUNCH_PRUNED_K(2) break;
-            case 3: CRF_LAUNCH_PRUNED_K(3) break;
-            default: CRF_LAUNCH_PRUNED_K(4) break;
-        }
-        if (info) info->kernel_name = "kraskov_direct_kernel<pruned>";
-    } else if (use_dxt && kk <= 4) {
+    if (use_dxt && kk <= 4) {
         switch (kk) {
             case 1:
                 if (ti4) {
@@ -1095,7 +979,7 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
 #undef CRF_LAUNCH_DIRECT_DXT
 #undef CRF_LAUNCH_DIRECT_DXT_TI
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info && !prune) info->kernel_name = "kraskov_direct_kernel";
+    if (info) info->kernel_name = "kraskov_direct_kernel";
     return hipGetLastError();
 }
 

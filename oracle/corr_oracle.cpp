@@ -778,6 +778,22 @@ int oracle_ensemble_stat(int kind, const float* const* fields, int es, size_t nu
     return 0;
 }
 
+/*
+ * Benchmark helper (bench.py cpu_baseline, "bound" variant): copies every member volume with the SAME static OpenMP
+ * partition over voxels the field loops use, so that with OMP_PROC_BIND / OMP_PLACES set each thread first-touches -- and
+ * thereby places on its own NUMA node -- the pages it will read.  dst volumes must be untouched allocations.
+ */
+int oracle_first_touch_copy(const float* const* src_members, float* const* dst_members, int cs, int64_t n) {
+    if (!src_members || !dst_members || cs < 1 || n < 0) return 1;
+    for (int c = 0; c < cs; c++) {
+        const float* s = src_members[c];
+        float* d = dst_members[c];
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < n; v++) d[v] = s[v];
+    }
+    return 0;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

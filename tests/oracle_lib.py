@@ -181,6 +181,19 @@ class Oracle:
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
 
+    def first_touch_copy(self, members):
+        """A copy of [cs, ...] float32 volumes whose pages were first touched by the OpenMP threads that will read them
+        (same static partition over voxels as the field loops): NUMA placement for a bound cpu_baseline run."""
+        members = np.ascontiguousarray(members, np.float32)
+        cs = members.shape[0]
+        n = members[0].size
+        out = np.empty(members.shape, np.float32)          # untouched pages (large allocation: fresh mmap)
+        src = (C.c_void_p * cs)(*[members[c].ctypes.data for c in range(cs)])
+        dst = (C.c_void_p * cs)(*[out[c].ctypes.data for c in range(cs)])
+        self.lib.oracle_first_touch_copy.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int64]
+        assert self.lib.oracle_first_touch_copy(src, dst, cs, n) == 0
+        return out
+
     def ensemble_stat(self, kind, members):
         members = _members(members)
         ptrs = (C.c_void_p * len(members))(*[m.ctypes.data for m in members])

@@ -161,37 +161,6 @@ def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, ti4,
     assert engine.last_kernel_name() == expected
 
 
-@pytest.mark.parametrize("points", ["1", "2", "4"])
-@pytest.mark.parametrize("cs", [16, 17, 20, 33, 47, 48, 64, 65, 72, 100, 127, 128])
-def test_kraskov_x_ordered_sweeps_with_early_exit(engine, oracle, monkeypatch, cs, points):
-    """The tile-free kernel with x-ordered candidate lists and the wave-uniform early exit (CRF_KRASKOV_PRUNE): the
-    K smallest distances -- and so every count -- must be those of the full sweep: tie-free data, the box ensemble (exact
-    ties: the exit fires after a handful of candidates on the plateaus), a NaN voxel, both estimators, 1 / 2 / 4 points
-    per sweep, member counts around the list padding (multiples of 8) and the step width (4)."""
-    monkeypatch.setenv("CRF_KRASKOV_PRUNE", "1")
-    monkeypatch.setenv("CRF_KRASKOV_DIRECT", "1")
-    monkeypatch.setenv("CRF_KRASKOV_PRUNE_TI", points)
-    for k in (1, 2, 3, 4):
-        for estimator in (1, 2):
-            ens = synth.normal_ensemble(16, 6, 5, cs, seed=90 * cs + k)
-            ens[3 % cs, 1, 2, 3] = np.nan
-            _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
-                   f"pruned KSG-{estimator} cs={cs} k={k} points={points}", ref_xyz=(2, 1, 0), k=k,
-                   kraskov_estimator_index=estimator, min_identical=0.99)
-    assert engine.last_kernel_name() == "kraskov_direct_kernel<pruned>"
-    box = synth.box_ensemble(16, 6, 5, cs, seed=cs)
-    for ref in [(5, 2, 1), (0, 0, 0)]:
-        _check(engine, oracle, box, Measure.KMI_CORRELATION_COEFFICIENT, oracle_lib.KMI_CC,
-               f"pruned box ensemble cs={cs} ref={ref}", ref_xyz=ref, k=3, min_identical=0.98)
-    # a reference vector with exact ties in x (equal x distances: the lists break them by member index)
-    ens = synth.normal_ensemble(16, 6, 5, cs, seed=7 * cs)
-    engine.set_grid(16, 6, 5, cs)
-    engine.upload_members(ens)
-    vec = np.repeat(np.arange((cs + 1) // 2, dtype=np.float32), 2)[:cs].copy()
-    got = engine.compute(Measure.MUTUAL_INFORMATION_KRASKOV, reference_values=vec, k=3).reshape(-1)
-    assert_close(got, oracle.field(oracle_lib.MI_KRASKOV, ens, vec, k=3), f"pruned, tied reference vector cs={cs}")
-
-
 @pytest.mark.parametrize("dxt", [None, "0", "1"])
 @pytest.mark.parametrize("cs", [65, 72, 79, 80, 81, 88, 111, 112, 113, 127, 128, 129, 140])
 def test_kraskov_distance_table_boundary(engine, oracle, monkeypatch, cs, dxt):

@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--measures", nargs="*", default=["pearson", "spearman", "kendall", "mi_binned", "mi_kraskov"])
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--symmetric", action="store_true", help="SEPARATE_SYMMETRIC field mode (two ensembles)")
+    ap.add_argument("--kraskov-k", type=int, default=0,
+                    help="fixed k for the Kraskov estimator (default: the reference's ceil(3 cs / 100), which steps "
+                         "with the member count); also prints ms / cs^2")
     args = ap.parse_args()
     xs, ys, zs = args.grid
     n = xs * ys * zs
@@ -45,7 +48,7 @@ def main():
         for name in args.measures:
             measure = ca.Measure(ca.MEASURE_IDS.index(name))
             iters = 2 if name == "mi_kraskov" else args.iters
-            kw = dict(k=ca.default_kraskov_k(cs), symmetric=args.symmetric)
+            kw = dict(k=args.kraskov_k or ca.default_kraskov_k(cs), symmetric=args.symmetric)
             if name == "mi_binned":
                 mm = eng.member_minmax()
                 kw.update(minmax_ref=mm, minmax_query=eng.secondary_member_minmax() if args.symmetric else mm,
@@ -58,7 +61,10 @@ def main():
             torch.cuda.synchronize()
             ms, cnt = eng.take_kernel_time()
             row.append(ms / cnt)
-        print(f"{cs:7d} " + " ".join(f"{v:12.3f}" for v in row), flush=True)
+        extra = ""
+        if args.kraskov_k and "mi_kraskov" in args.measures:
+            extra = f"   k={args.kraskov_k}: {row[args.measures.index('mi_kraskov')] / (cs * cs) * 1e3:.3f} us per member^2"
+        print(f"{cs:7d} " + " ".join(f"{v:12.3f}" for v in row) + extra, flush=True)
         del eng, block, members
 
 
