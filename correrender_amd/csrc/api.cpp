@@ -914,6 +914,19 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     return rc;
 }
 
+int crf_compute_prepared_device(crf_context* c, const crf_params* p, int first_slot, int count, void* const* device_outs,
+                                void* stream) {
+    if (!c || !p || !device_outs) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (count < 0 || first_slot < 0 || first_slot + count > CRF_PREPARED_SLOTS)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("slots [%d, %d) outside [0, %d)", first_slot, first_slot + count, CRF_PREPARED_SLOTS));
+    crf_params local = *p;
+    for (int i = 0; i < count; i++) {
+        local.prepared_slot = first_slot + i + 1;
+        if (int r = crf_compute_device(c, &local, nullptr, device_outs[i], stream)) return r;
+    }
+    return CRF_OK;
+}
+
 int crf_prepare_device(crf_context* c, const crf_params* p, const void* device_reference_values, int slot, void* stream) {
     if (slot < 0 || slot >= CRF_PREPARED_SLOTS)
         return fail(c, CRF_ERR_ARGUMENT, fmt("slot %d outside [0,%d)", slot, CRF_PREPARED_SLOTS));

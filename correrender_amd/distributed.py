@@ -221,6 +221,39 @@ class ShardedCorrField:
         for i, p in enumerate(points):
             self._pending.append((p, ("batch", b, i, i == r - 1, None if slots is None else (slots[i], int(measure)))))
 
+    def compute_batch(self, measure, outs, points, **kw):
+        """compute() for the next len(points) reference points of ONE prepared batch (prefetch_batch(points, prepare=...)),
+        outs[i] receiving point i.  When the engine can launch prepared evaluations in one call
+        (crf_compute_prepared_device) the host pays one call for the whole batch instead of one per evaluation; any other
+        state (rows not prepared, a batch boundary inside, an engine without that call) takes the per-point path."""
+        points = [tuple(p) for p in points]
+        n = len(points)
+        head = self._pending[:n]
+        fast = (n > 0 and len(head) == n and hasattr(self.engine, "compute_prepared_device") and
+                all(isinstance(slot, tuple) and slot[4] is not None and slot[4][1] == int(measure) and p == pt
+                    for (p, slot), pt in zip(head, points)) and
+                len({slot[1] for _, slot in head}) == 1 and
+                [slot[4][0] for _, slot in head] == list(range(head[0][1][4][0], head[0][1][4][0] + n)))
+        if not fast:
+            for out, p in zip(outs, points):
+                self.compute(measure, out, p, **kw)
+            return outs
+        if int(measure) in _BINNED and "minmax_ref" not in kw:
+            mm = self.global_minmax()
+            kw = dict(kw, minmax_ref=mm, minmax_query=mm)
+        del self._pending[:n]
+        b = head[0][1][1]
+        cur = self._torch.cuda.current_stream(self.device) if self._cuda else None
+        if cur is not None and head[0][1][2] == 0:
+            cur.wait_event(self._batch_ready[b])
+        self.engine.compute_prepared_device(measure, list(outs), head[0][1][4][0],
+                                            stream=cur.cuda_stream if cur is not None else 0, **kw)
+        if cur is not None and head[-1][1][3]:
+            ev = self._torch.cuda.Event()
+            ev.record(cur)
+            self._batch_done[b] = ev
+        return outs
+
     def compute(self, measure, out, ref_xyz, **kw):
         """Evaluates this rank's slab for the GLOBAL reference point ref_xyz into `out` (z_count*ys*xs floats), on the
         current torch stream, stream-ordered, without host synchronisation."""

@@ -256,6 +256,20 @@ class CorrField:
             self._keep_ref = keep
         return out
 
+    def compute_prepared_device(self, measure, outs, first_slot: int, *, stream: int = 0, k=None,
+                                kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None):
+        """crf_compute_prepared_device: len(outs) prepared evaluations (slots first_slot ...) launched back to back with
+        one call; outs[i] receives evaluation i (the same tensor may be given several times)."""
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, "single")
+        p, _ = self._params(measure, None, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query, None, 0)
+        for t in outs:
+            if t.numel() != self.num_voxels or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("every out must be a contiguous CUDA float32 tensor of xs*ys*zs elements")
+        ptrs = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        self._check(self._lib.crf_compute_prepared_device(self._ctx, C.byref(p), int(first_slot), len(outs), ptrs,
+                                                          C.c_void_p(stream)))
+        return outs
+
     PREPARED_SLOTS = 64   # CRF_PREPARED_SLOTS
 
     def prepare_device(self, measure, slot: int, ref=None, *, device_reference=None, stream: int = 0, k=None,

@@ -190,6 +190,13 @@ int crf_compute_device(crf_context* ctx, const crf_params* params, const void* d
 int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* device_reference_values, int slot,
                        void* stream);
 
+/* Launches `count` prepared evaluations back to back with ONE call: evaluation i reads the tables crf_prepare_device left
+ * in slot first_slot + i and writes device_outs[i] (params: as given to crf_prepare_device, prepared_slot is ignored).
+ * The host-side cost of a pipelined driver then is one call per batch instead of one per evaluation -- at 8 GPUs a
+ * 256^3 x 64 evaluation is 0.09 ms per device, the same order as a Python-level call. */
+int crf_compute_prepared_device(crf_context* ctx, const crf_params* params, int first_slot, int count,
+                                void* const* device_outs, void* stream);
+
 /* ---- several GPUs behind ONE caller thread ------------------------------------------------------------------------
  * The reference is a single process that calls its calculators from the render thread with a caller-owned host buffer
  * (src/Volume/VolumeData.cpp:1214-1226, 1469-1472).  A crf_group gives such a caller N devices: the GLOBAL grid is cut

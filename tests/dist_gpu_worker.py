@@ -65,6 +65,28 @@ def main():
                 diff = np.flatnonzero(~((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))))
                 bad.append((rank, measure.name, (x, y, z), int(diff.size), int(diff[0]), float(got[diff[0]]),
                             float(want[diff[0]])))
+    # compute_batch: the prepared evaluations of a whole batch launched with one library call
+    # (crf_compute_prepared_device), two batches double-buffered as in bench.py's throughput mode
+    for measure in (Measure.PEARSON, Measure.KENDALL, Measure.MUTUAL_INFORMATION_KRASKOV):
+        points = [(1, 2, 0), (12, 8, zs // 2), (23, 15, zs - 1), (5, 5, 1), (7, 0, 3), (20, 9, zs - 2), (2, 14, 4)]
+        first, second = points[:4], points[4:]
+        prep = (measure, dict(k=2))
+        outs = [torch.empty(xs * ys * zl, dtype=torch.float32, device=dev) for _ in points]
+        sharded.prefetch_batch(first, prepare=prep)
+        sharded.prefetch_batch(second, prepare=prep)          # exchanged while the first batch is consumed
+        sharded.compute_batch(measure, outs[:4], first, k=2)
+        sharded.compute_batch(measure, outs[4:], second, k=2)
+        torch.cuda.synchronize()
+        for (x, y, z), out in zip(points, outs):
+            kw = dict(k=2, minmax_ref=gmm) if measure != Measure.PEARSON else {}
+            want = oracle.field(int(measure), ens, ens[:, z, y, x].copy(), **kw)[z0 * ys * xs:(z0 + zl) * ys * xs]
+            got = out.cpu().numpy()
+            if int(measure) <= 2:
+                ok = ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+            else:
+                ok = np.allclose(got, want, rtol=1e-5, atol=1e-6, equal_nan=True)
+            if not ok:
+                bad.append((rank, "compute_batch " + measure.name, (x, y, z)))
     flag = torch.tensor([len(bad)])
     dist.all_reduce(flag)
     eng.close()
