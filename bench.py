@@ -436,21 +436,22 @@ def cpu_baseline(args, eng, members, out, measure, last_pt, kwargs):
     # (a two-socket host under-states the reference otherwise): a child process, because libgomp reads OMP_PROC_BIND /
     # OMP_PLACES when it is loaded
     try:
-        cpu["bound"] = cpu_baseline_bound(sample, ref_values, m, use_ref, okw if not use_ref else {})
+        cpu["bound"] = cpu_baseline_bound(sample, ref_values, m, use_ref, okw if not use_ref else {}, threads)
     except Exception as e:  # the bound variant is an extra: never fail the bench line over it
         cpu["bound"] = {"error": str(e)[:200]}
     cpu["first_touch"] = "one thread (the sample is copied from the GPU by the main thread)"
     return cpu, parity
 
 
-def cpu_baseline_bound(sample, ref_values, m, use_ref, okw):
+def cpu_baseline_bound(sample, ref_values, m, use_ref, okw, threads):
     import numpy as np
     shm = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path("/tmp")
     path = shm / f"crf_cpu_sample_{os.getpid()}.npz"
     try:
         np.savez(path, sample=sample, ref_values=ref_values, m=m, use_ref=use_ref,
                  okw=json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in okw.items()}))
-        env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        # the same thread count as the unbound run above (libgomp's default would be every logical CPU)
+        env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores", OMP_NUM_THREADS=str(threads))
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-child", str(path)], env=env,
                            capture_output=True, text=True, timeout=600)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

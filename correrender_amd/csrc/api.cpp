@@ -638,7 +638,7 @@ int crf_gather_reference(crf_context* c, int x, int y, int z, float* host_out) {
 //   host    a persistent pool of copier threads (crf_pool.h) moves each finished range from the staging buffer into
 //           the caller's buffer, and while it waits for a range it faults the destination pages of the ranges ahead in
 //           (MADV_POPULATE_WRITE batches the faults; transparent huge pages are requested for the buffer first).
-// Ranges shrink towards the end so that the last copy -- the only one not hidden behind a kernel -- is small.
+// Range sizes are staggered over two streams so that kernel ends alternate and the last copy is small (ensure_host_ranges).
 // CRF_HOST_PATH=dma keeps results in HBM and copies each range with the DMA engine instead (also used when a post-pass
 // has to read the result back: CRF_FLAG_ABSOLUTE_VALUE).
 constexpr int kMadvPopulateWrite = 23;  // MADV_POPULATE_WRITE (Linux 5.14), not in every libc header
@@ -954,12 +954,28 @@ int ensure_host_ranges(crf_context* c) {
         per = (per + 1023) & ~size_t(1023);
         for (size_t at = per; at < n && int(first.size()) < kMaxHostChunks; at += per) first.push_back(at);
     } else {
-        // shares of 64: 16 14 11 8 6 4 3 2 -- each range at least ~2/3 of the one before it (the copier threads move a
-        // range about twice as fast as the link delivers the next one), the last one 1/32 of the result
-        static const int kShares[] = {16, 14, 11, 8, 6, 4, 3, 2};
+        // Shares of 64, consecutive ranges alternating between two streams: 3 6 6 6 6 6 6 6 6 5 4 2 2.  The two streams'
+        // kernels run concurrently and share the link; with the FIRST range half the size of the others the kernel ends
+        // alternate (B0 A0 B1 A1 ...), so results land every ~1/11 of the run from early on, the copier threads always
+        // have a landed range to move, and the last ranges are small: only their copy is not hidden behind a kernel.
+        // Same-process A/B at 256^3 (tools/measure_host_path.py ab, profiles/r03_host_boundary_variants.txt), resident /
+        // fresh destination: 13 ranges 1.326 / 1.391 ms; 11 ranges (4 8x6 6 3 2 1) 1.336 / 1.452; 8 staggered ranges
+        // 1.369 / 1.467; 8 shrinking ranges 16 14 11 8 6 4 3 2 (pairs end together) 1.378 / 1.527; 8 equal 1.450 / 1.644.
+        std::vector<int> kShares = {3, 6, 6, 6, 6, 6, 6, 6, 6, 5, 4, 2, 2};
+        if (const char* e = getenv("CRF_HOST_SHARES")) {  // experiments: comma-separated shares of 64
+            std::vector<int> v;
+            int sum = 0;
+            for (const char* q = e; *q;) {
+                v.push_back(atoi(q));
+                sum += v.back();
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+            if (sum == 64 && v.size() >= 1 && v.size() <= size_t(kMaxHostChunks)) kShares = v;
+        }
         size_t acc = 0;
-        for (int j = 0; j + 1 < int(sizeof kShares / sizeof *kShares); j++) {
-            acc += size_t(kShares[j]);
+        for (int j = 0; j + 1 < int(kShares.size()); j++) {
+            acc += size_t(kShares[size_t(j)]);
             const size_t at = (n / 64 * acc + 1023) & ~size_t(1023);
             if (at > first.back() && at < n) first.push_back(at);
         }
@@ -1123,6 +1139,7 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
         return 0;
     };
     c->copy_pool->start(copy_job);
+    const double t_pool = trace ? since() : 0.0;
     // every exit below has to release the copier threads first
     auto abort_copy = [&](int rc) {
         for (int j = 0; j < ranges; j++) c->chunk_ready[j].store(-1, std::memory_order_release);
@@ -1132,6 +1149,7 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
 
     // 1. reference-side tables, once
     if (int r = compute_impl(c, p, device_reference_values, nullptr, nullptr, 1u, -1, ov)) return abort_copy(r);
+    const double t_prep = trace ? since() : 0.0;
     if (two_streams) {
         if (hipEventRecord(c->prep_done, c->stream) != hipSuccess || hipStreamWaitEvent(c->stream2, c->prep_done, 0) != hipSuccess)
             return abort_copy(fail(c, CRF_ERR_DEVICE, "ordering the second stream after the preparation failed"));
@@ -1143,7 +1161,7 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
         RangeScope scope(c);
         for (int j = 0; j < ranges; j++) {
             scope.select(j);
-            hipStream_t s = (two_streams && (j & 1)) ? c->stream2 : c->stream;
+            hipStream_t s = (two_streams && !(j & 1)) ? c->stream2 : c->stream;  // range 0 on the second stream
             float* out = out_base + c->chunk_first[j];
             if (int r = compute_impl(c, p, nullptr, out, s, 2u, -1)) return abort_copy(r);
             if (p->flags & CRF_FLAG_ABSOLUTE_VALUE)
@@ -1168,8 +1186,8 @@ int compute_to_host(crf_context* c, const crf_params* p, const void* device_refe
         if (trace) fprintf(stderr, "crf_compute: range %d (%zu voxels) landed at %.0f us\n", j, c->chunk_first[j + 1] - c->chunk_first[j], since());
     }
     c->copy_pool->wait();
-    if (trace) fprintf(stderr, "crf_compute: launches issued by %.0f us, copied out by %.0f us (%d ranges, %d copier threads)\n",
-                       t_issued, since(), ranges, threads);
+    if (trace) fprintf(stderr, "crf_compute: copier pool started by %.0f us, preparation launched by %.0f us, launches issued by %.0f us, "
+                               "copied out by %.0f us (%d ranges, %d copier threads)\n", t_pool, t_prep, t_issued, since(), ranges, threads);
     return CRF_OK;
 }
 

@@ -213,6 +213,7 @@ def test_whole_1024cubed_grid_on_one_gpu_members_of_4_gib(engine, oracle):
                 (Measure.MUTUAL_INFORMATION_BINNED, oracle_lib.MI_BINNED, False,
                  dict(num_bins=80, minmax_ref=mm, minmax_query=mm), dict(num_bins=80, minmax_ref=mm))):
             out.fill_(-7.0)
+            torch.cuda.synchronize()                                           # the engine computes on its own stream
             engine.compute_device(m, out, ref_xyz, **kw)
             torch.cuda.synchronize()
             (assert_bit_exact if exact else assert_close)(out[didx].cpu().numpy(), oracle.field(om, cols, ref_values, **okw),

@@ -58,8 +58,51 @@ def one():
                       "fresh_ms": round(med(t_fresh) * 1e3, 3), "device_only_ms": round(dev * 1e3, 3)}))
 
 
+def ab():
+    """Same-process A/B of range layouts (the tables are rebuilt when the members are bound again): three rounds over
+    the variants, medians per variant."""
+    import numpy as np
+    import torch
+    import correrender_amd as ca
+    xs = ys = zs = 256
+    cs = 64
+    eng = ca.CorrField(0)
+    eng.set_grid(xs, ys, zs, cs)
+    members = torch.empty((cs, zs, ys, xs), dtype=torch.float32, device="cuda")
+    for c in range(cs):
+        eng.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, 1)
+    torch.cuda.synchronize()
+    variants = {k: {} for k in (os.environ.get("CRF_AB_SHARES") or
+                                "16,14,11,8,6,4,3,2;6,12,12,12,10,6,4,2;4,8,8,8,8,8,8,6,3,2,1;8,8,8,8,8,8,8,8").split(";")}
+    res = {k: [] for k in variants}
+    fresh_res = {k: [] for k in variants}
+    resident = np.zeros((zs, ys, xs), np.float32)
+    for rnd in range(3):
+        for shares in variants:
+            os.environ["CRF_HOST_SHARES"] = shares
+            eng.bind_members(members)            # drops the range tables
+            for i in range(3):
+                eng.compute(ca.Measure.PEARSON, (10, 20, 30), out=resident)
+            for i in range(12):
+                t0 = time.perf_counter()
+                eng.compute(ca.Measure.PEARSON, (10 + i, 20, 30), out=resident)
+                res[shares].append(time.perf_counter() - t0)
+            for i in range(8):
+                fresh = np.empty((zs, ys, xs), np.float32)
+                t0 = time.perf_counter()
+                eng.compute(ca.Measure.PEARSON, (10 + i, 20, 30), out=fresh)
+                fresh_res[shares].append(time.perf_counter() - t0)
+                del fresh
+    med = lambda v: sorted(v)[len(v) // 2]
+    for shares in variants:
+        print(json.dumps({"shares_of_64": shares, "resident_ms": round(med(res[shares]) * 1e3, 3),
+                          "resident_min_ms": round(min(res[shares]) * 1e3, 3), "fresh_ms": round(med(fresh_res[shares]) * 1e3, 3)}))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "one":
+    if len(sys.argv) > 1 and sys.argv[1] == "ab":
+        ab()
+    elif len(sys.argv) > 1 and sys.argv[1] == "one":
         one()
     else:
         import torch
