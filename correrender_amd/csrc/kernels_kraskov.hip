@@ -355,7 +355,10 @@ constexpr int direct_min_waves(int K, int TI, bool SYM) {
     return K <= 2 ? 4 : (K == 3 ? 3 : (K == 4 ? 2 : (K <= 32 ? 3 : 1)));
 }
 
-template <int K, int TI, bool SYM = false, bool DXT = false>
+// STAGE (not SYM, share mode): the block copies a tile's cs x 64 values into LDS once (each wave fetches every fourth
+// member, non-temporal) and every sweep of every wave reads them from there -- one HBM / L2 read per value instead of
+// 2 cs / TI + 1 reads served by L1 / L2 (measured at the fabric counters: 1.18x the algorithmic bytes at 4 points per sweep).
+template <int K, int TI, bool SYM = false, bool DXT = false, bool STAGE = false>
 __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_direct_kernel(const float* const* __restrict__ members,
                                                             const float* const* __restrict__ members_x,
                                                             const double* __restrict__ prep_px,
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
     double* s_px = reinterpret_cast<double*>(smem);  // member order
     double* s_spx = s_px + cs;                       // ascending
     double* s_nq = s_spx + cs;
+    float* s_tile = reinterpret_cast<float*>(s_nq + cs);  // STAGE: [cs][64], the current tile's values
     // partial sums of the block's 4 tiles, one slot per (tile, wave): [16][64] x (sum_x, sum_y, NaN flag)
     __shared__ double s_sum_x[16 * 64];
     __shared__ double s_sum_y[16 * 64];
@@ -411,6 +415,24 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
         if (tile >= tiles || (!share && t4 > 0)) continue;
         const size_t v = tile * 64 + lane;
         const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
+        if constexpr (STAGE) {
+            __syncthreads();  // every wave has finished reading the previous tile
+#pragma unroll 1
+            for (int m0 = wave; m0 < cs; m0 += 4 * 8) {
+                float stage[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) stage[q] = load_member_nt(members[m0 + 4 * q < cs ? m0 + 4 * q : cs - 1], bytes, off);
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (m0 + 4 * q < cs) s_tile[(m0 + 4 * q) * 64 + lane] = stage[q];
+            }
+            __syncthreads();
+        }
+        // one member value of this lane's voxel: from the staged tile or from memory (L1 / L2 after the first touch)
+        auto value_of = [&](int m) -> float {
+            if constexpr (STAGE) return s_tile[m * 64 + lane];
+            else return load_member_cached(members[m], bytes, off);
+        };
         bool is_nan = false;
         double sum_x = 0.0, sum_y = 0.0;
         // share: the 4 * passes items (tile, TI points) of the group are dealt to the waves round-robin
@@ -422,7 +444,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
 #pragma unroll
             for (int t = 0; t < TI; t++) {
                 const int ii = (i0 + t < cs) ? i0 + t : cs - 1;
-                const float y = load_member_cached(members[ii], bytes, off);
+                const float y = value_of(ii);
                 is_nan |= y != y;
                 if constexpr (SYM) {
                     const float x = load_member_cached(members_x[ii], bytes, off);
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                 float yb[JB], xb[SYM ? JB : 1];
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
-                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                    yb[u] = value_of(j0 + u < cs ? j0 + u : cs - 1);
                     if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                 }
                 // A candidate past the end gets +inf coordinates (one uniform select per candidate, not one per pair;
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
 #pragma unroll 2
                 for (int j = 0; j < cs; j++) {
                     const double pxj = SYM ? double(load_member_cached(members_x[j], bytes, off)) + s_px[j] : s_px[j];
-                    const double pyj = double(load_member_cached(members[j], bytes, off)) + s_nq[j];
+                    const double pyj = double(value_of(j)) + s_nq[j];
 #pragma unroll
                     for (int t = 0; t < TI; t++) {
                         const double ax = fabs(pxi[t] - pxj), ay = fabs(pyi[t] - pyj);
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(256, direct_min_waves(K, TI, SYM)) void kraskov_dir
                 float yb[JB], xb[SYM ? JB : 1];
 #pragma unroll
                 for (int u = 0; u < JB; u++) {
-                    yb[u] = load_member_cached(members[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
+                    yb[u] = value_of(j0 + u < cs ? j0 + u : cs - 1);
                     if constexpr (SYM) xb[u] = load_member_cached(members_x[j0 + u < cs ? j0 + u : cs - 1], bytes, off);
                 }
                 auto candidate_c = [&](int u) {
@@ -889,6 +911,14 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     const size_t cap = cap_env && atoi(cap_env) > 0 ? size_t(atoi(cap_env)) : 65536;
     const unsigned blocks = unsigned(groups < cap ? groups : cap);
     const int share = direct_share_tiles();
+    // The tile staged in LDS (table kernels, 4 points per sweep): every member value is fetched ONCE.  Up to 64 members the
+    // 16 KB tile costs no occupancy -- 256^3: 64 members k = 3 / 4 26.3 / 29.7 ms against 26.2 / 31.6 ms, 32 members 7.0
+    // against 7.3 -- beyond that it does (80 / 100 members k = 3: 46.4 / 80.0 against 40.2 / 64.6 ms); k = 1, 2 keep their
+    // 8-point sweeps (64 members k = 2: 23.2 ms staged with 4 points against 21.6).  CRF_KRASKOV_STAGE=0/1 overrides.
+    const char* stage_env = getenv("CRF_KRASKOV_STAGE");
+    const bool stage_fits = lds + size_t(cs) * 256 + kDirectSumBytes <= 64 * 1024;
+    const bool stage = share && stage_fits && (stage_env ? *stage_env == '1' : (cs <= 64 && kk >= 3));
+    const size_t lds_stage = lds + size_t(cs) * 256;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
 #define CRF_LAUNCH_DIRECT(K, TI)                                                                                    \
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, prep, psi, \
@@ -906,6 +936,9 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     hipLaunchKernelGGL((kraskov_direct_kernel<K, TI, false, true>), dim3(blocks), dim3(256), lds, s, d_members, nullptr, \
                        prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
 #define CRF_LAUNCH_DIRECT_DXT(K) CRF_LAUNCH_DIRECT_DXT_TI(K, 8)
+#define CRF_LAUNCH_STAGED(K)                                                                                              \
+    hipLaunchKernelGGL((kraskov_direct_kernel<K, 4, false, true, true>), dim3(blocks), dim3(256), lds_stage, s, d_members, \
+                       nullptr, prep, psi, noise_query, d_out, num_voxels, cs, a.k, a.estimator, int(a.to_cc), a.c_term, share)
     // 4 points per sweep instead of 8 for K = 3 and 4: half the registers (94 / 119 instead of 156 / 188: 5 / 4 waves per
     // SIMD instead of 3 / 2) and one s_load_dwordx8 per candidate row -- 256^3 with the table: k = 4 at 32 / 48 / 64 / 80
     // members 8.7 / 17.5 / 30.5 / 46.4 ms against 10.6 / 21.6 / 37.9 / 57.7 ms, k = 3 at 48 / 64 / 80: 14.8 / 25.8 / 39.3
@@ -917,7 +950,14 @@ hipError_t launch_mi_kraskov_direct(const float* const* d_members, int cs, size_
     const bool ti4_k4 = ti4_env ? *ti4_env == '1' : true;
     const bool ti4_k3_plain = ti4_env && *ti4_env == '1';
     const bool ti4 = ti4_table;
-    if (use_dxt && kk <= 4) {
+    if (use_dxt && kk <= 4 && stage) {
+        switch (kk) {
+            case 1: CRF_LAUNCH_STAGED(1); break;
+            case 2: CRF_LAUNCH_STAGED(2); break;
+            case 3: CRF_LAUNCH_STAGED(3); break;
+            default: CRF_LAUNCH_STAGED(4); break;
+        }
+    } else if (use_dxt && kk <= 4) {
         switch (kk) {
             case 1:
                 if (ti4) {

@@ -161,6 +161,27 @@ def test_kraskov_kernel_variants(engine, oracle, monkeypatch, variant, dxt, ti4,
     assert engine.last_kernel_name() == expected
 
 
+@pytest.mark.parametrize("stage", ["0", "1"])
+@pytest.mark.parametrize("cs", [16, 20, 33, 47, 64, 65, 100])
+def test_kraskov_tile_staged_in_lds_or_not(engine, oracle, monkeypatch, cs, stage):
+    """The tile-free kernel with the voxel tile staged in LDS (default up to 64 members for k >= 3) and without, forced
+    either way for every k: ragged member counts (the staging loop fetches every fourth member per wave, 8 at a time),
+    a NaN voxel, both estimators, the box ensemble."""
+    monkeypatch.setenv("CRF_KRASKOV_DIRECT", "1")
+    monkeypatch.setenv("CRF_KRASKOV_STAGE", stage)
+    for k in (1, 2, 3, 4):
+        for estimator in (1, 2):
+            ens = synth.normal_ensemble(16, 6, 5, cs, seed=50 * cs + k)
+            ens[5 % cs, 2, 3, 4] = np.nan                      # not the reference voxel (a NaN there is undefined in the reference)
+            _check(engine, oracle, ens, Measure.MUTUAL_INFORMATION_KRASKOV, oracle_lib.MI_KRASKOV,
+                   f"stage={stage} KSG-{estimator} cs={cs} k={k}", ref_xyz=(2, 1, 0), k=k,
+                   kraskov_estimator_index=estimator, min_identical=0.99)
+    assert engine.last_kernel_name() == "kraskov_direct_kernel"
+    box = synth.box_ensemble(16, 6, 5, cs, seed=cs + 1)
+    _check(engine, oracle, box, Measure.KMI_CORRELATION_COEFFICIENT, oracle_lib.KMI_CC,
+           f"stage={stage} box ensemble cs={cs}", ref_xyz=(5, 2, 1), k=3, min_identical=0.98)
+
+
 @pytest.mark.parametrize("dxt", [None, "0", "1"])
 @pytest.mark.parametrize("cs", [65, 72, 79, 80, 81, 88, 111, 112, 113, 127, 128, 129, 140])
 def test_kraskov_distance_table_boundary(engine, oracle, monkeypatch, cs, dxt):
