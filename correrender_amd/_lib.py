@@ -64,6 +64,7 @@ SYMBOLS = {
     "crf_gather_reference_device": (C.c_int, [_VOIDP, C.c_int, C.c_int, C.c_int, _VOIDP, _VOIDP]),
     "crf_gather_reference_rows_device": (C.c_int, [_VOIDP, C.POINTER(C.c_int32), C.c_int, _VOIDP, _VOIDP]),
     "crf_prepare_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_int, _VOIDP]),
+    "crf_prepare_rows_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, C.c_int, C.c_int, _VOIDP]),
     "crf_compute_prepared_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.c_int, C.c_int, C.POINTER(_VOIDP), _VOIDP]),
     "crf_compute": (C.c_int, [_VOIDP, C.POINTER(CrfParams), C.POINTER(C.c_float)]),
     "crf_compute_device": (C.c_int, [_VOIDP, C.POINTER(CrfParams), _VOIDP, _VOIDP, _VOIDP]),

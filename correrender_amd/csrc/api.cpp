@@ -914,6 +914,20 @@ int crf_compute_device(crf_context* c, const crf_params* p, const void* device_r
     return rc;
 }
 
+int crf_prepare_rows_device(crf_context* c, const crf_params* p, const void* device_rows, int first_slot, int count,
+                            void* stream) {
+    if (!c || !p || !device_rows) return fail(c, CRF_ERR_ARGUMENT, "null argument");
+    if (count < 0 || first_slot < 0 || first_slot + count > CRF_PREPARED_SLOTS)
+        return fail(c, CRF_ERR_ARGUMENT, fmt("slots [%d, %d) outside [0, %d)", first_slot, first_slot + count, CRF_PREPARED_SLOTS));
+    crf_params local = *p;
+    local.reference_values = nullptr;
+    local.prepared_slot = 0;
+    const float* rows = static_cast<const float*>(device_rows);
+    for (int i = 0; i < count; i++)
+        if (int r = crf_prepare_device(c, &local, rows + size_t(i) * size_t(c->cs), first_slot + i, stream)) return r;
+    return CRF_OK;
+}
+
 int crf_compute_prepared_device(crf_context* c, const crf_params* p, int first_slot, int count, void* const* device_outs,
                                 void* stream) {
     if (!c || !p || !device_outs) return fail(c, CRF_ERR_ARGUMENT, "null argument");

@@ -551,6 +551,100 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 65..128 members, ONE sorting network over 32-bit composites (r03).  The split kernel above sorts two chunks of 64-bit
+// composites and pays for the cross-chunk order with 64 binary searches, a histogram pass and two LDS key columns
+// (~7.9 k vector instructions per voxel at 128 members).  Here a composite is (key & ~127) | slot: the order-preserving
+// key with its 7 low bits dropped, the member's slot in their place -- 128 composites fit in 128 registers and ONE
+// Batcher network over u32 min / max sorts them.  Two members whose keys agree in the upper 25 bits (values within
+// 2^-16 relative of each other: ~4 % of the voxels of N(0,1) data have such a pair) would be ordered by slot, which is
+// wrong: the dropped bits are parked in the lane's LDS column, and after the sort every adjacent pair with equal upper
+// bits is put right from them (a wave-uniform branch per position, taken for a few positions per wave).  A run of three
+// such keys, or two keys that are equal in all 32 bits (a tie: fractional ranks), defers the voxel to the exact kernel
+// through the todo list, like the split kernels do.  Ranks of a tie-free voxel are positions + 1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float* const* __restrict__ members,
+                                                                     const float* __restrict__ prep,
+                                                                     float* __restrict__ out, size_t num_voxels, int cs,
+                                                                     uint32_t* __restrict__ todo) {
+    static_assert(N <= 128 && N % 16 == 0, "slots are 7 bits");
+    __shared__ uint8_t pos_of[N * 64];   // [slot][lane]: 0-based position of the member in the sorted order
+    __shared__ uint8_t low_of[N * 64];   // [slot][lane]: the 7 key bits the composite dropped
+    constexpr int SURE = N - 16;         // slots that are members for every cs of this instantiation (N - 16 < cs <= N)
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const bool active = v < num_voxels;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    bool is_nan = false, defer = false;
+    uint32_t a[N];
+    {
+        float y[N];  // all loads first (slots past cs: out-of-range offset, no memory request)
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const bool real = e < SURE || e < cs;
+            y[e] = load_member_nt(members[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
+        }
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            const float yc = y[e] + 0.0f;  // -0.0 -> +0.0: key equality is float equality
+            const bool real = e < SURE || e < cs;
+            is_nan |= real && (yc != yc);
+            const uint32_t key = real ? orderable_key(yc) : 0xFFFFFFFFu;  // pads sort last (a NaN voxel is flagged anyway)
+            low_of[e * 64 + lane] = uint8_t(key & 0x7Fu);
+            a[e] = (key & ~0x7Fu) | uint32_t(e);
+            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet32<N>::sort(a);
+    __builtin_amdgcn_sched_barrier(0);
+    // adjacent composites with equal upper bits: order them by the dropped bits (positions q, q + 1 both real members)
+    bool prev_close = false;
+#pragma unroll
+    for (int q = 0; q + 1 < N; q++) {
+        const bool both_real = q + 1 < SURE || q + 1 < cs;
+        const bool close = both_real && ((a[q] ^ a[q + 1]) < 128u);
+        if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
+            if (close) {
+                const uint32_t sa = a[q] & 0x7Fu, sb = a[q + 1] & 0x7Fu;
+                const uint32_t la = low_of[sa * 64 + lane], lb = low_of[sb * 64 + lane];
+                defer |= (la == lb) | prev_close;  // a true tie, or a run of three: the exact kernel's business
+                if (la > lb) {
+                    const uint32_t t = a[q];
+                    a[q] = a[q + 1];
+                    a[q + 1] = t;
+                }
+            }
+        }
+        prev_close = close;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        pos_of[(a[q] & 0x7Fu) * 64 + lane] = uint8_t(q);
+        if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float r[N];
+    {
+        uint32_t raw[N];  // all reads first, then the conversions (see spearman_kernel)
+#pragma unroll
+        for (int e = 0; e < N; e++) raw[e] = pos_of[e * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < N; e++) r[e] = (e < SURE || e < cs) ? float(raw[e] + 1u) : 0.0f;
+    }
+    float res = pearson_tail<N, false, SURE>(r, prep, cs);
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (active) {
+        if (defer && !is_nan) {
+            todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        } else {
+            store_result_nt(out + v, res);
+        }
+    }
+}
+
 // discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..CH-1), one 64-bit "seen" set
 template <int CH, int SURE = 0>
 __device__ __forceinline__ int32_t chunk_inversions(const composite_t (&a)[CH], int count, bool exact) {
@@ -859,6 +953,17 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             if (d_todo && env_waves(2) != 0) {
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const bool wide_exact = env_exact() && getenv("CRF_RANK_EXACT");  // only on request
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+#define CRF_LAUNCH_U32(NN)                                                                                            \
+    hipLaunchKernelGGL((spearman_u32_kernel<NN, 2>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out, num_voxels, \
+                       cs, d_todo)
+                if (env_flag("CRF_RANK_U32") && cs > 64) {  // experiment: one network over 32-bit composites
+                    if (cs <= 80) CRF_LAUNCH_U32(80);
+                    else if (cs <= 96) CRF_LAUNCH_U32(96);
+                    else if (cs <= 112) CRF_LAUNCH_U32(112);
+                    else CRF_LAUNCH_U32(128);
+                } else
+#undef CRF_LAUNCH_U32
                 if (cs <= 72)
                     launch_spearman_split<64, 8, 2>(env_exact(), d_members, d_prep, d_out, num_voxels, cs, s, d_todo);
                 else if (cs <= 80)

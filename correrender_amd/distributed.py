@@ -203,6 +203,9 @@ class ShardedCorrField:
             slots = [b * self._slots_per_batch + i for i in range(r)]
 
         def prepare_rows(stream_ptr):
+            if hasattr(self.engine, "prepare_rows_device"):     # one library call for the whole batch
+                self.engine.prepare_rows_device(measure, rows, slots[0], r, stream=stream_ptr, **pkw)
+                return
             for i in range(r):
                 self.engine.prepare_device(measure, slots[i], device_reference=rows[i], stream=stream_ptr, **pkw)
 

@@ -256,6 +256,17 @@ class CorrField:
             self._keep_ref = keep
         return out
 
+    def prepare_rows_device(self, measure, rows, first_slot: int, count: int, *, stream: int = 0, k=None,
+                            kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None):
+        """crf_prepare_rows_device: rows[i] (a [>= count, cs] contiguous CUDA float32 tensor) prepared into slot
+        first_slot + i, one call for the whole batch."""
+        minmax_ref, minmax_query = self._binned_ranges(measure, minmax_ref, minmax_query, "single")
+        p, _ = self._params(measure, None, k, kraskov_estimator_index, num_bins, minmax_ref, minmax_query, None, 0)
+        if not rows.is_cuda or not rows.is_contiguous() or rows.dim() != 2 or rows.shape[1] != self.cs or rows.shape[0] < count:
+            raise ValueError("rows must be a contiguous [>= count, cs] CUDA float32 tensor")
+        self._check(self._lib.crf_prepare_rows_device(self._ctx, C.byref(p), C.c_void_p(rows.data_ptr()), int(first_slot),
+                                                      int(count), C.c_void_p(stream)))
+
     def compute_prepared_device(self, measure, outs, first_slot: int, *, stream: int = 0, k=None,
                                 kraskov_estimator_index=1, num_bins=80, minmax_ref=None, minmax_query=None):
         """crf_compute_prepared_device: len(outs) prepared evaluations (slots first_slot ...) launched back to back with

@@ -190,6 +190,11 @@ int crf_compute_device(crf_context* ctx, const crf_params* params, const void* d
 int crf_prepare_device(crf_context* ctx, const crf_params* params, const void* device_reference_values, int slot,
                        void* stream);
 
+/* crf_prepare_device for `count` reference vectors with ONE call: row i of device_rows (cs floats each, contiguous rows --
+ * e.g. the buffer crf_gather_reference_rows_device filled and an all-reduce completed) is prepared into slot
+ * first_slot + i.  params: the evaluation's settings (reference point and reference_values are not read). */
+int crf_prepare_rows_device(crf_context* ctx, const crf_params* params, const void* device_rows, int first_slot, int count,
+                            void* stream);
 /* Launches `count` prepared evaluations back to back with ONE call: evaluation i reads the tables crf_prepare_device left
  * in slot first_slot + i and writes device_outs[i] (params: as given to crf_prepare_device, prepared_slot is ignored).
  * The host-side cost of a pipelined driver then is one call per batch instead of one per evaluation -- at 8 GPUs a

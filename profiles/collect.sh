@@ -3,7 +3,7 @@
 # PMC passes for HBM traffic (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC slot limits, MI355X_MICROARCH.md).
 # Usage: bash profiles/collect.sh <tag> [bench args...]      -> gpurun_out/prof_<tag>/
 set -eo pipefail
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

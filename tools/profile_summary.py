@@ -25,9 +25,11 @@ def rows(pattern):
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("pearson_reg_kernel", "pearson_stream_kernel", "pearson_prep_kernel", "spearman_kernel", "kendall_kernel",
-                "mi_binned_kernel", "mi_kraskov_kernel", "minmax_kernel", "synth_box_kernel", "gather_reference_kernel",
-                "spearman_split_kernel", "kendall_split_kernel", "direct_rank_kernel", "fill_kernel"):
+    for key in ("pearson_reg_lds_kernel", "pearson_reg_kernel", "pearson_relay_kernel", "pearson_big_kernel",
+                "pearson_stream_kernel", "pearson_prep_kernel", "spearman_split_kernel", "kendall_split_kernel",
+                "spearman_prep_kernel", "kendall_prep_kernel", "spearman_kernel", "kendall_kernel", "mi_binned_kernel",
+                "kraskov_direct_kernel", "kraskov_sorted_kernel", "kraskov_prep_kernel", "mi_kraskov_kernel", "minmax_kernel",
+                "synth_box_kernel", "gather_reference_kernel", "direct_rank_kernel", "fill_kernel"):
         if key in name:
             return key
     return name[-60:]
@@ -39,6 +41,10 @@ def main():
     for r in rows(os.path.join(out, "trace", "**", "*kernel_trace.csv")):
         dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"# rocprofv3 summary ({' '.join(sys.argv[2:])})\n")
+    print("Three separate runs of the same command (profiles/collect.sh): durations from the `--kernel-trace --stats` run ONLY;\n"
+          "FETCH_SIZE from the `--pmc FETCH_SIZE` run, WRITE_SIZE from the `--pmc WRITE_SIZE` run (kernels run slower under\n"
+          "counter collection: their durations are not reported).\n")
+    print("Table 1 -- kernel durations, pass `rocprofv3 --kernel-trace --stats`:\n")
     print("| kernel | launches | avg us | median us | min us | total ms |")
     print("|---|---|---|---|---|---|")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -50,7 +56,8 @@ def main():
             if r.get("Counter_Name") == name:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         pmc[name] = {k: statistics.mean(v) for k, v in acc.items()}
-    print("\n| kernel | FETCH_SIZE KiB/launch (raw) | x2-corrected GB | WRITE_SIZE KiB/launch | GB |")
+    print("\nTable 2 -- HBM traffic per launch, passes `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE`:\n")
+    print("| kernel | FETCH_SIZE KiB/launch (raw) | x2-corrected GB | WRITE_SIZE KiB/launch | GB |")
     print("|---|---|---|---|---|")
     for k in sorted(set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"])):
         f = pmc["FETCH_SIZE"].get(k, float("nan"))
