@@ -551,6 +551,51 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     }
 }
 
+// u32 networks for the member counts between the ones crf_device.h instantiates (sortnet.inc has every multiple of 8)
+#define CRF_CE(i, j)                           \
+    {                                          \
+        const uint32_t lo_ = a[i], hi_ = a[j]; \
+        a[i] = lo_ < hi_ ? lo_ : hi_;          \
+        a[j] = lo_ < hi_ ? hi_ : lo_;          \
+    }
+#define CRF_SORTNET32(NN)                                                        \
+    template <>                                                                  \
+    struct SortNet32<NN> {                                                       \
+        static __device__ __forceinline__ void sort(uint32_t (&a)[NN]);          \
+    };
+CRF_SORTNET32(40)
+CRF_SORTNET32(56)
+CRF_SORTNET32(72)
+CRF_SORTNET32(88)
+CRF_SORTNET32(104)
+CRF_SORTNET32(120)
+#undef CRF_SORTNET32
+__device__ __forceinline__ void SortNet32<40>::sort(uint32_t (&a)[40]) {
+#define CRF_SORTNET_N 40
+#include "sortnet.inc"
+}
+__device__ __forceinline__ void SortNet32<56>::sort(uint32_t (&a)[56]) {
+#define CRF_SORTNET_N 56
+#include "sortnet.inc"
+}
+__device__ __forceinline__ void SortNet32<72>::sort(uint32_t (&a)[72]) {
+#define CRF_SORTNET_N 72
+#include "sortnet.inc"
+}
+__device__ __forceinline__ void SortNet32<88>::sort(uint32_t (&a)[88]) {
+#define CRF_SORTNET_N 88
+#include "sortnet.inc"
+}
+__device__ __forceinline__ void SortNet32<104>::sort(uint32_t (&a)[104]) {
+#define CRF_SORTNET_N 104
+#include "sortnet.inc"
+}
+__device__ __forceinline__ void SortNet32<120>::sort(uint32_t (&a)[120]) {
+#define CRF_SORTNET_N 120
+#include "sortnet.inc"
+}
+#undef CRF_CE
+
 // ---------------------------------------------------------------------------------------------------------------
 // 65..128 members, ONE sorting network over 32-bit composites (r03).  The split kernel above sorts two chunks of 64-bit
 // composites and pays for the cross-chunk order with 64 binary searches, a histogram pass and two LDS key columns
@@ -563,38 +608,45 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
 // such keys, or two keys that are equal in all 32 bits (a tie: fractional ranks), defers the voxel to the exact kernel
 // through the todo list, like the split kernels do.  Ranks of a tie-free voxel are positions + 1.
 // ---------------------------------------------------------------------------------------------------------------
-template <int N, int MIN_WAVES>
+template <int N, int MIN_WAVES, bool EXACT>  // EXACT: cs == N, no pads
 __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float* const* __restrict__ members,
                                                                      const float* __restrict__ prep,
                                                                      float* __restrict__ out, size_t num_voxels, int cs,
                                                                      uint32_t* __restrict__ todo) {
-    static_assert(N <= 128 && N % 16 == 0, "slots are 7 bits");
+    static_assert(N <= 128 && N % 8 == 0, "slots are 7 bits");
     __shared__ uint8_t pos_of[N * 64];   // [slot][lane]: 0-based position of the member in the sorted order
     __shared__ uint8_t low_of[N * 64];   // [slot][lane]: the 7 key bits the composite dropped
-    constexpr int SURE = N - 16;         // slots that are members for every cs of this instantiation (N - 16 < cs <= N)
+    constexpr int SURE = EXACT ? N : N - 8;  // slots that are members for every cs of this instantiation (N - 8 < cs <= N)
     const int lane = threadIdx.x;
     const size_t v = size_t(blockIdx.x) * 64 + lane;
     const bool active = v < num_voxels;
     const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
     bool is_nan = false, defer = false;
-    uint32_t a[N];
-    {
-        float y[N];  // all loads first (slots past cs: out-of-range offset, no memory request)
+    uint32_t key_min = 0xFFFFFFFFu, key_max = 0u;
+    uint32_t a[N];  // the loaded values, then their composites, in place (one register per member)
 #pragma unroll
-        for (int e = 0; e < N; e++) {
-            const bool real = e < SURE || e < cs;
-            y[e] = load_member_nt(members[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset);
-        }
+    for (int e = 0; e < N; e++) {  // all loads first (slots past cs: out-of-range offset, no memory request)
+        const bool real = e < SURE || e < cs;
+        a[e] = __float_as_uint(load_member_nt(members[real ? e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset));
+    }
 #pragma unroll
-        for (int e = 0; e < N; e++) {
-            const float yc = y[e] + 0.0f;  // -0.0 -> +0.0: key equality is float equality
-            const bool real = e < SURE || e < cs;
-            is_nan |= real && (yc != yc);
-            const uint32_t key = real ? orderable_key(yc) : 0xFFFFFFFFu;  // pads sort last (a NaN voxel is flagged anyway)
-            low_of[e * 64 + lane] = uint8_t(key & 0x7Fu);
-            a[e] = (key & ~0x7Fu) | uint32_t(e);
-            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int e = 0; e < N; e++) {
+        const float yc = __uint_as_float(a[e]) + 0.0f;  // -0.0 -> +0.0: key equality is float equality
+        const bool real = e < SURE || e < cs;
+        const uint32_t okey = orderable_key(yc);
+        // NaNs map beyond the infinities at either end of the key range; tracked on the keys, here and now (a float
+        // compare `yc != yc` gets sunk to the end of the kernel by the compiler, which then keeps all N values alive)
+        key_min = min(key_min, okey);
+        key_max = max(key_max, real ? okey : 0u);
+        const uint32_t key = real ? okey : 0xFFFFFFFFu;  // pads sort last
+        low_of[e * 64 + lane] = uint8_t(key & 0x7Fu);
+        a[e] = (key & ~0x7Fu) | uint32_t(e);
+        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // pinned here (an empty asm that "modifies" the flag): otherwise the min / max chain is sunk to the kernel's end
+        uint32_t nan_flag = (key_min < 0x007FFFFFu || key_max > 0xFF800000u) ? 1u : 0u;
+        asm volatile("" : "+v"(nan_flag));
+        is_nan = nan_flag != 0u;
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet32<N>::sort(a);
@@ -606,6 +658,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
         const bool both_real = q + 1 < SURE || q + 1 < cs;
         const bool close = both_real && ((a[q] ^ a[q + 1]) < 128u);
         if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
+            asm volatile("" ::: "memory");  // a real branch: left alone the compiler if-converts the block (30 instructions per position)
             if (close) {
                 const uint32_t sa = a[q] & 0x7Fu, sb = a[q + 1] & 0x7Fu;
                 const uint32_t la = low_of[sa * 64 + lane], lb = low_of[sb * 64 + lane];
@@ -627,14 +680,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
     }
     __builtin_amdgcn_sched_barrier(0);
     float r[N];
-    {
-        uint32_t raw[N];  // all reads first, then the conversions (see spearman_kernel)
 #pragma unroll
-        for (int e = 0; e < N; e++) raw[e] = pos_of[e * 64 + lane];
+    for (int e = 0; e < N; e++) a[e] = pos_of[e * 64 + lane];  // all reads first, then the conversions (see spearman_kernel)
 #pragma unroll
-        for (int e = 0; e < N; e++) r[e] = (e < SURE || e < cs) ? float(raw[e] + 1u) : 0.0f;
-    }
-    float res = pearson_tail<N, false, SURE>(r, prep, cs);
+    for (int e = 0; e < N; e++) r[e] = (e < SURE || e < cs) ? float(a[e] + 1u) : 0.0f;
+    float res = pearson_tail<N, EXACT, SURE>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
         if (defer && !is_nan) {
@@ -886,7 +936,7 @@ void launch_kendall_prep(const RefSource& ref, const float* const* d_members, in
 hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref, float* d_prep,
                            uint32_t* d_todo, float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end,
                            LaunchInfo* info) {
-    bool split = false;
+    bool split = false, u32 = false;
     if (cs == 1) {
         if (!ref.run()) return hipSuccess;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
@@ -924,6 +974,27 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             }
             break;
         case 64:
+            // 33..64 members: the u32 network too (256^3: 40 members 0.77 -> 0.70 ms, 48: 0.95 -> 0.85, 56: 1.16 -> 1.02,
+            // 64: 1.22 -> 1.17, 33: unchanged); CRF_RANK_U32=0 keeps the 64-bit-composite kernels
+            if (d_todo && cs > 32 && env_int("CRF_RANK_U32", 1) != 0) {
+                (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+                const unsigned blocks = unsigned((num_voxels + 63) / 64);
+#define CRF_LAUNCH_U32_SMALL(NN)                                                                                          \
+    if (cs == NN)                                                                                                        \
+        hipLaunchKernelGGL((spearman_u32_kernel<NN, 2, true>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,   \
+                           num_voxels, cs, d_todo);                                                                     \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((spearman_u32_kernel<NN, 2, false>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,  \
+                           num_voxels, cs, d_todo)
+                if (cs <= 40) { CRF_LAUNCH_U32_SMALL(40); }
+                else if (cs <= 48) { CRF_LAUNCH_U32_SMALL(48); }
+                else if (cs <= 56) { CRF_LAUNCH_U32_SMALL(56); }
+                else { CRF_LAUNCH_U32_SMALL(64); }
+#undef CRF_LAUNCH_U32_SMALL
+                launch_spearman_n<64, 2>(d_members, d_prep, d_out, num_voxels, cs, s, d_todo);  // voxels with ties
+                u32 = true;
+                break;
+            }
             // measured at 256^3 (profiles/tuning_r01.md): cs = 64: monolithic unguarded 1.75 ms vs split 1.87-1.96 ms;
             // cs = 48: monolithic guarded 5.26 ms vs split 1.65 ms; cs = 40: 5.45 ms vs 1.43 ms
             if (d_todo && cs > 32 && (cs < 64 || env_split64())) {
@@ -954,14 +1025,28 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
                 (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
                 const bool wide_exact = env_exact() && getenv("CRF_RANK_EXACT");  // only on request
                 const unsigned blocks = unsigned((num_voxels + 63) / 64);
-#define CRF_LAUNCH_U32(NN)                                                                                            \
-    hipLaunchKernelGGL((spearman_u32_kernel<NN, 2>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out, num_voxels, \
-                       cs, d_todo)
-                if (env_flag("CRF_RANK_U32") && cs > 64) {  // experiment: one network over 32-bit composites
-                    if (cs <= 80) CRF_LAUNCH_U32(80);
-                    else if (cs <= 96) CRF_LAUNCH_U32(96);
-                    else if (cs <= 112) CRF_LAUNCH_U32(112);
-                    else CRF_LAUNCH_U32(128);
+#define CRF_LAUNCH_U32(NN)                                                                                               \
+    if (cs == NN)                                                                                                        \
+        hipLaunchKernelGGL((spearman_u32_kernel<NN, 2, true>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,   \
+                           num_voxels, cs, d_todo);                                                                     \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((spearman_u32_kernel<NN, 2, false>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,  \
+                           num_voxels, cs, d_todo)
+                // One network over 32-bit composites (spearman_u32_kernel, padded to a multiple of 8): 256^3, split-sort ->
+                // u32 network: 72 members 1.76 -> 1.49 ms, 80: 2.01 -> 1.74, 96: 2.66 -> 2.10, 100: 2.86 -> 2.31, 112: 3.28
+                // -> 2.50, 128: 3.65 -> 3.17; 512^3 x 128 (BASELINE configs[3]) 28.8 -> 25.1 ms, bit-identical fields.
+                // CRF_RANK_U32=0 keeps the split-sort kernels.
+                const int u32_env = env_int("CRF_RANK_U32", -1);
+                if (cs > 64 && u32_env != 0) {
+                    if (cs <= 72) { CRF_LAUNCH_U32(72); }
+                    else if (cs <= 80) { CRF_LAUNCH_U32(80); }
+                    else if (cs <= 88) { CRF_LAUNCH_U32(88); }
+                    else if (cs <= 96) { CRF_LAUNCH_U32(96); }
+                    else if (cs <= 104) { CRF_LAUNCH_U32(104); }
+                    else if (cs <= 112) { CRF_LAUNCH_U32(112); }
+                    else if (cs <= 120) { CRF_LAUNCH_U32(120); }
+                    else { CRF_LAUNCH_U32(128); }
+                    u32 = true;
                 } else
 #undef CRF_LAUNCH_U32
                 if (cs <= 72)
@@ -988,7 +1073,7 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
             break;
     }
     if (ev_end) (void)hipEventRecord(ev_end, s);
-    if (info) info->kernel_name = split ? "spearman_split_kernel" : "spearman_kernel";
+    if (info) info->kernel_name = u32 ? "spearman_u32_kernel" : split ? "spearman_split_kernel" : "spearman_kernel";
     return hipGetLastError();
 }
 

@@ -114,3 +114,60 @@ def test_rank_single_member_is_one(engine, measure):
 def test_rank_64cubed_16_members(engine, oracle, measure, omeasure):
     ens = synth.box_ensemble(64, 64, 64, 16)
     _check(engine, oracle, ens, (8, 8, 32), measure, omeasure, f"{measure.name} 64^3x16")
+
+
+@pytest.mark.parametrize("u32", ["0", "1"])
+@pytest.mark.parametrize("cs", [33, 40, 47, 48, 56, 63, 64, 65, 72, 73, 80, 81, 95, 96, 100, 104, 111, 120, 127, 128])
+def test_spearman_values_that_agree_in_their_upper_bits(engine, oracle, monkeypatch, cs, u32):
+    """The 33..128-member Spearman kernel sorts 32-bit composites that carry only the upper 25 bits of a member's key;
+    members whose values agree in those bits are put in order from the dropped bits afterwards, runs of three and exact
+    ties go to the exact kernel.  Voxels full of such values: pairs one / a few ulps apart (positive, negative, across
+    zero, denormals), runs of three and four close values, close values next to exact ties, a NaN, +-inf, the largest
+    and smallest members affected.  Both kernels forced (CRF_RANK_U32 = 0: split-sort, 1: u32 network)."""
+    monkeypatch.setenv("CRF_RANK_U32", u32)
+    rng = np.random.default_rng(1000 + cs)
+    xs, ys, zs = 16, 8, 4
+    ens = rng.standard_normal((cs, zs, ys, xs)).astype(np.float32)
+    flat = ens.reshape(cs, -1)
+    n = flat.shape[1]
+
+    def ulps(v, k):
+        return (np.float32(v).view(np.int32) + np.int32(k)).view(np.float32) if v >= 0 else (np.float32(v).view(np.int32) - np.int32(k)).view(np.float32)
+
+    for vox in range(0, n, 3):
+        members = rng.permutation(cs)
+        kind = (vox // 3) % 8
+        base = flat[members[0], vox]
+        if kind == 0:      # a pair 1 ulp apart
+            flat[members[1], vox] = ulps(base, 1)
+        elif kind == 1:    # a pair 100 ulps apart (same upper 25 bits or not, as it falls)
+            flat[members[1], vox] = ulps(base, 100)
+        elif kind == 2:    # a run of three within 5 ulps
+            flat[members[1], vox] = ulps(base, 2)
+            flat[members[2], vox] = ulps(base, 5)
+        elif kind == 3:    # a run of four, one of them an exact tie
+            flat[members[1], vox] = ulps(base, 1)
+            flat[members[2], vox] = ulps(base, 1)
+            flat[members[3], vox] = ulps(base, 3)
+        elif kind == 4:    # many pairs at once, all over the range
+            for i in range(0, min(cs - 1, 40), 2):
+                flat[members[i + 1], vox] = ulps(flat[members[i], vox], 1 + i % 7)
+        elif kind == 5:    # around zero: +-denormals, +0 / -0
+            flat[members[0], vox] = np.float32(1e-45)
+            flat[members[1], vox] = np.float32(-1e-45)
+            flat[members[2], vox] = np.float32(0.0)
+            flat[members[3], vox] = np.float32(3e-45)
+        elif kind == 6:    # the extremes: the two largest and the two smallest close to each other, infinities
+            order = np.argsort(flat[:, vox])
+            flat[order[-1], vox] = ulps(flat[order[-2], vox], 1)
+            flat[order[0], vox] = ulps(flat[order[1], vox], 1 if flat[order[1], vox] < 0 else -1)
+            if vox % 2:
+                flat[members[5], vox] = np.inf
+                flat[members[6], vox] = -np.inf
+        else:              # a NaN voxel with close pairs in it
+            flat[members[1], vox] = ulps(base, 1)
+            flat[members[2], vox] = np.nan
+    ref_xyz = (1, 0, 0)                                  # voxel 1: untouched by the loop above
+    _check(engine, oracle, ens, ref_xyz, Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman close values cs={cs} u32={u32}")
+    expect = "spearman_u32_kernel" if u32 == "1" else ("spearman_kernel" if cs == 64 else "spearman_split_kernel")
+    assert engine.last_kernel_name() == expect
