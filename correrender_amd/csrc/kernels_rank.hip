@@ -651,6 +651,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
     __builtin_amdgcn_sched_barrier(0);
     SortNet32<N>::sort(a);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < N; q++) asm volatile("" : "+v"(a[q]));  // the network ends here: nothing below is mixed into it
     // adjacent composites with equal upper bits: order them by the dropped bits (positions q, q + 1 both real members)
     bool prev_close = false;
 #pragma unroll
@@ -673,6 +675,10 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
         prev_close = close;
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the sorted composites are pinned here: otherwise the address arithmetic of the scatter below is hoisted into the
+    // end of the network, one more live register per member (116 B of scratch per lane at 128 members)
+#pragma unroll
+    for (int q = 0; q < N; q++) asm volatile("" : "+v"(a[q]));
 #pragma unroll
     for (int q = 0; q < N; q++) {
         pos_of[(a[q] & 0x7Fu) * 64 + lane] = uint8_t(q);
@@ -1033,8 +1039,8 @@ hipError_t launch_spearman(const float* const* d_members, int cs, size_t num_vox
         hipLaunchKernelGGL((spearman_u32_kernel<NN, 2, false>), dim3(blocks), dim3(64), 0, s, d_members, d_prep, d_out,  \
                            num_voxels, cs, d_todo)
                 // One network over 32-bit composites (spearman_u32_kernel, padded to a multiple of 8): 256^3, split-sort ->
-                // u32 network: 72 members 1.76 -> 1.49 ms, 80: 2.01 -> 1.74, 96: 2.66 -> 2.10, 100: 2.86 -> 2.31, 112: 3.28
-                // -> 2.50, 128: 3.65 -> 3.17; 512^3 x 128 (BASELINE configs[3]) 28.8 -> 25.1 ms, bit-identical fields.
+                // u32 network: 72 members 1.73 -> 1.35 ms, 80: 1.89 -> 1.52, 96: 2.60 -> 2.02, 100: 2.77 -> 2.24, 112: 3.08
+                // -> 2.39, 128: 3.50 -> 2.72; 512^3 x 128 (BASELINE configs[3]) 27.6 -> 21.5 ms, bit-identical fields.
                 // CRF_RANK_U32=0 keeps the split-sort kernels.
                 const int u32_env = env_int("CRF_RANK_U32", -1);
                 if (cs > 64 && u32_env != 0) {
