@@ -29,6 +29,19 @@
 
 namespace crf {
 
+// Ends a sorting network for the compiler: an empty asm "modifies" every element, so nothing that follows is mixed into the
+// network's last stages.  Left alone the compiler starts the scans / searches that consume the sorted array while the last
+// exchanges are still pending, the live ranges of both overlap, and a network over N values needs ~2N registers
+// (spearman_u32_kernel: 116 B of scratch per lane at 128 members, 25.1 -> 21.5 ms at 512^3 x 128 once they were gone;
+// mi_binned_kernel: 40 B of scratch at 64 / 128 members gone, three waves per SIMD instead of two at 96 members: 2.33 ->
+// 2.15 ms at 256^3).  Measured neutral for the other rank kernels, slightly negative (+2 %) for the two-field kernels of
+// kernels_symmetric*.hip, which therefore do without it.
+template <class T, int N>
+__device__ __forceinline__ void pin_array(T (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) asm volatile("" : "+v"(a[i]));
+}
+
 constexpr uint32_t kPadKey = 0xFFFFFFFFu;  // sorts after every real value (orderable_key(+inf) = 0xFF800000)
 
 // NaNs sort to the ends: a positive NaN has an orderable key above key(+inf) = 0xFF800000, a negative NaN one below
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_kernel(const float* co
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
+    pin_array(a);  // the network ends here (crf_device.h)
     __builtin_amdgcn_sched_barrier(0);
     bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
     if constexpr (EXACT) {
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_kernel(const float* con
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet<N>::sort(a);
+    pin_array(a);  // the network ends here (crf_device.h)
     __builtin_amdgcn_sched_barrier(0);
     bool is_nan = composite_key(a[0]) < 0x007FFFFFu;
     if constexpr (EXACT) {
@@ -437,6 +452,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         load_chunk<CH, true, false>(a, members, nullptr, 0, cs, bytes, byte_offset);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CH>::sort(a);
+        pin_array(a);  // the network ends here (crf_device.h)
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         load_chunk<CHB, EXACT, false, SURE_B>(b, members, nullptr, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CHB>::sort(b);
+        pin_array(b);  // the network ends here (crf_device.h)
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
         constexpr int G = 4;  // searches in flight (8: scratch in the 64 + 64 and 32 + 32 kernels)
@@ -650,9 +667,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
     }
     __builtin_amdgcn_sched_barrier(0);
     SortNet32<N>::sort(a);
+    pin_array(a);  // the network ends here (crf_device.h)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < N; q++) asm volatile("" : "+v"(a[q]));  // the network ends here: nothing below is mixed into it
     // adjacent composites with equal upper bits: order them by the dropped bits (positions q, q + 1 both real members)
     bool prev_close = false;
 #pragma unroll
@@ -760,6 +776,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         load_chunk<CH, true, true>(a, members, prep, 0, cs, bytes, byte_offset);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CH>::sort(a);
+        pin_array(a);  // the network ends here (crf_device.h)
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
 #pragma unroll
@@ -782,6 +799,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         load_chunk<CHB, EXACT, true, SURE_B>(b, members, prep, CH, cs, bytes, byte_offset_b);
         __builtin_amdgcn_sched_barrier(0);
         SortNet<CHB>::sort(b);
+        pin_array(b);  // the network ends here (crf_device.h)
         __builtin_amdgcn_sched_barrier(0);
         uint32_t prev = 0;
         constexpr int G = 4;  // see spearman_split_kernel
