@@ -23,6 +23,9 @@
 
 namespace crf {
 
+constexpr int kPrepZeroFilled = 1280;  // a_e = 0 for cs <= e < this: the padded slots of the register and split kernels
+static_assert(kPrepZeroFilled >= kMaxRegisterMembers, "padded slots of the register kernels");
+
 // ---------------------------------------------------------------------------------------------------------
 // Reference-side preparation: one wave.  d_prep[e] = a_e for e < cs.
 // ---------------------------------------------------------------------------------------------------------
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void pearson_prep_kernel(RefSource src, const 
     const float meanX = sh[0], sdX = sh[1];
     for (int e = threadIdx.x; e < cs; e += blockDim.x) prep[e] = invNm1 * ((x[e] - meanX) / sdX);
     // padded slots of the guarded register kernels multiply by a_e = 0 (see pearson_reg_kernel)
-    for (int e = cs + threadIdx.x; e < kMaxRegisterMembers; e += blockDim.x) prep[e] = 0.0f;
+    for (int e = cs + threadIdx.x; e < kPrepZeroFilled; e += blockDim.x) prep[e] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -268,6 +271,267 @@ __global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_lds_kernel(const f
             if (t < nt) r += prep[R + t] * (tail[t][threadIdx.x] / sdY);
     }
     if (v0 < num_voxels) store_result_nt(out + v0, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 321..1216 members (r03): G = 2 or 4 LANES per voxel.  A wave owns 64 / G voxels; lane group g (lanes g * 64 / G ...)
+// holds members [g * S, g * S + S) of them, S = R + L slots per lane: R in registers and L in the lane's LDS column,
+// exactly the storage of the 176..320-member kernels above, which run at two waves per SIMD and 70-88 % of the HBM
+// peak -- instead of one wave per SIMD with 384 values in VGPRs + AGPRs (37-56 %), an 8-wave relay through LDS
+// (385..512 members, 37 %) or three sweeps over the members (beyond 512: 3x the algorithmic bytes).
+// The three passes of computePearson2<float> are sequential fp32 sums over the members, so each pass is a relay of
+// G stages inside the wave: in stage gg every lane runs the chain over its own S slots, starting from the value that
+// group gg - 1 handed over (ds_bpermute, no LDS memory), and only group gg's result is kept; the other groups compute
+// throw-away values in that stage (no traps, nothing stored).  Same operations in the same order as the reference,
+// every member value fetched once.  What does not lie on a chain -- products, deviations, quotients -- is done once
+// and two slots at a time (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: the same IEEE operations per element), which
+// pays for the repeated chain stages: 12.9 vector instructions per slot at G = 2 against 12 per member in
+// pearson_reg_kernel.  A load instruction is issued per member under the owning group's exec mask (the descriptor is
+// wave-uniform), 256 / G bytes each.
+//   PAD   cs lies in (G * S - PAD, G * S]: only the last PAD slots of the last group can be padding (they read 0, their
+//         deviation is forced to 0 and a_e = 0 for e >= cs: every pass adds +0 for them, as in pearson_reg_kernel).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float from_lane(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+constexpr int kSplitMaxMembers = 4 * 304;  // 1216
+
+template <int R, int L, int G, int PAD, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void pearson_split_kernel(const float* const* __restrict__ members,
+                                                                       const float* __restrict__ prep,
+                                                                       float* __restrict__ out, uint32_t num_voxels,
+                                                                       int cs) {
+    static_assert(R % 2 == 0 && L % 2 == 0 && PAD % 2 == 0 && 64 % G == 0, "slots are handled in pairs");
+    constexpr int S = R + L;        // slots per lane
+    constexpr int VW = 64 / G;      // voxels per wave
+    constexpr int kSure = S - PAD;  // slots below are members in every lane group
+    static_assert(kSure >= 0 && G * S <= kPrepZeroFilled, "a_e is zero-filled up to kPrepZeroFilled");
+    extern __shared__ float tail_dyn[];  // L rows of 256 floats: slot R + t of thread x is tail[t][x]
+    float(*tail)[256] = reinterpret_cast<float(*)[256]>(tail_dyn);
+    const int lane = int(threadIdx.x) & 63;
+    const int g = lane / VW;
+    const uint32_t v0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * uint32_t(VW) + uint32_t(lane % VW);
+    const uint32_t byte_offset = v0 * 4u, bytes = num_voxels * 4u;  // lanes past the end read 0 and store nothing
+    // slot i of this lane is a member iff i < mine.  (Laundered before each phase that tests it: left alone the compiler
+    // evaluates all PAD tests once and keeps them as SGPR pairs across the kernel, which spill into VGPR lanes.)
+    int mine = cs - g * S;
+    const auto is_member = [&mine](int i) { return i < kSure || i < mine; };
+    f2 y[R / 2];
+    // the LDS tail first (global_load_lds: memory -> LDS without registers; lane l of the wave lands at row base + 4 l):
+    // loads return in order, so by the time the register loads issued below have been waited for these are done too
+    if constexpr (L > 0) {
+        const int wave_first = int(threadIdx.x) & ~63;
+        const uint32_t v_safe = v0 < num_voxels ? v0 : num_voxels - 1u;  // no descriptor bounds on this path
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+            if (g == gg) {
+#pragma unroll
+                for (int t = 0; t < L; t++) {
+                    const int e = gg * S + R + t;
+                    if (gg < G - 1 || R + t < kSure || e < cs) {
+                        typedef const float __attribute__((address_space(1)))* gptr_t;
+                        typedef float __attribute__((address_space(3)))* lptr_t;
+                        __builtin_amdgcn_global_load_lds((gptr_t)(members[e] + v_safe), (lptr_t)&tail[t][wave_first], 4, 0,
+                                                         kAuxNonTemporal);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int gg = 0; gg < G; gg++) {
+        if (g == gg) {  // this group's members, under its exec mask
+#pragma unroll
+            for (int i = 0; i < R; i++) {
+                const int e = gg * S + i;
+                float v = 0.0f;
+                if (gg < G - 1 || i < kSure) {
+                    v = load_member_nt(members[e], bytes, byte_offset);
+                } else if (e < cs) {  // uniform branch around a load that may be padding
+                    v = load_member_nt(members[e], bytes, byte_offset);
+                }
+                y[i / 2][i % 2] = v;
+            }
+        }
+    }
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    const int last_group_lane = (G - 1) * VW + lane % VW;  // where a pass's result ends up for this lane's voxel
+    // ---- pass 1: meanY += invN * y_e
+    float m = 0.0f;
+#pragma unroll
+    for (int gg = 0; gg < G; gg++) {
+        if (gg > 0) m = from_lane(m, lane - VW);
+        // laundered per stage: left alone the compiler computes the products once and keeps all S of them for the
+        // other stages (spills)
+        f2 scale = {invN, invN};
+        asm volatile("" : "+v"(scale));
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {
+            const f2 t = scale * y[k];
+            m += t[0];
+            m += t[1];
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L > 0) {
+            if (gg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail has landed (see above)
+            asm volatile("" : "+v"(mine));
+#pragma unroll
+            for (int t = 0; t < L; t += 2) {
+                f2 v = {tail[t][threadIdx.x], tail[t + 1][threadIdx.x]};
+                if (R + t >= kSure) {  // a padded row was not loaded: whatever the row holds is not a member value
+                    if (!is_member(R + t)) v[0] = 0.0f;
+                    if (!is_member(R + t + 1)) v[1] = 0.0f;
+                }
+                const f2 p = scale * v;
+                m += p[0];
+                m += p[1];
+                if ((t & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // (else all L rows are read up front)
+            }
+        }
+    }
+    const float meanY = from_lane(m, last_group_lane);
+    // ---- deviations in place (needed again, bit-identically, by pass 3)
+    {
+        const f2 mean2 = {meanY, meanY};
+        asm volatile("" : "+v"(mine));
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {
+            f2 d = y[k] - mean2;
+            if (2 * k >= kSure) {
+                if (!is_member(2 * k)) d[0] = 0.0f;
+                if (!is_member(2 * k + 1)) d[1] = 0.0f;
+            }
+            y[k] = d;
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L > 0) {
+            asm volatile("" : "+v"(mine));
+#pragma unroll
+            for (int t = 0; t < L; t++) {
+                float d = tail[t][threadIdx.x] - meanY;
+                if (R + t >= kSure && !is_member(R + t)) d = 0.0f;
+                tail[t][threadIdx.x] = d;
+                if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- pass 2: varY += (invNm1 * d_e) * d_e
+    float var = 0.0f;
+#pragma unroll
+    for (int gg = 0; gg < G; gg++) {
+        if (gg > 0) var = from_lane(var, lane - VW);
+        f2 scale = {invNm1, invNm1};
+        asm volatile("" : "+v"(scale));
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {
+            const f2 t = (scale * y[k]) * y[k];
+            var += t[0];
+            var += t[1];
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L > 0) {
+#pragma unroll
+            for (int t = 0; t < L; t += 2) {
+                const f2 d = {tail[t][threadIdx.x], tail[t + 1][threadIdx.x]};
+                const f2 p = (scale * d) * d;
+                var += p[0];
+                var += p[1];
+                if ((t & 6) == 6) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const float sdY = sqrtf(from_lane(var, last_group_lane));
+    // ---- pass 3: r += a_e * (d_e / sdY)
+    float r = 0.0f;
+    // exact_div needs sd in [2^-60, 2^60] and every non-zero deviation >= 2^-100 in magnitude (crf_device.h).
+    // exact_div_guard() infers the latter from |mean| >= 2^-70; a wave in which that fails -- a mean that is exactly 0
+    // is enough, and the benchmark's box ensemble has such voxels at 512 members -- looks at its deviations themselves
+    // before it gives up the exact path, whose alternative is expensive here (see the else branch).
+    bool exact = exact_div_guard(meanY, sdY);
+    constexpr bool kSecondLook = R + L < 304;  // (in the 304-slot instantiation it costs 0.3 KB of scratch per lane)
+    if (kSecondLook && !__all(exact)) {
+        uint32_t smallest = 0xFFFFFFFFu;  // min over the slots of (bits of |d|) - 1: a zero wraps to the maximum
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {
+            smallest = min(smallest, (__float_as_uint(y[k][0]) & 0x7FFFFFFFu) - 1u);
+            smallest = min(smallest, (__float_as_uint(y[k][1]) & 0x7FFFFFFFu) - 1u);
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L > 0) {
+#pragma unroll
+            for (int t = 0; t < L; t++) {
+                smallest = min(smallest, (__float_as_uint(tail[t][threadIdx.x]) & 0x7FFFFFFFu) - 1u);
+                if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // (a NaN or infinite member makes the mean and therefore sd NaN: the range test fails)
+        exact = sdY >= 0x1p-60f && sdY <= 0x1p60f && smallest >= __float_as_uint(0x1p-100f) - 1u;
+    }
+    if (__all(exact)) {  // exact quotients through one reciprocal per voxel
+        const float rcp = 1.0f / sdY;
+        const f2 rcp2 = {rcp, rcp}, sd2 = {sdY, sdY};
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {  // exact_div in place, two slots at a time
+            const f2 q0 = y[k] * rcp2;
+            const f2 rem = __builtin_elementwise_fma(-q0, sd2, y[k]);
+            y[k] = __builtin_elementwise_fma(rem, rcp2, q0);
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L > 0) {
+#pragma unroll
+            for (int t = 0; t < L; t++) {
+                tail[t][threadIdx.x] = exact_div(tail[t][threadIdx.x], sdY, rcp);
+                if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < G; gg++) {
+            if (gg > 0) r = from_lane(r, lane - VW);
+#pragma unroll
+            for (int k = 0; k < R / 2; k++) {
+                const f2 a = {prep[gg * S + 2 * k], prep[gg * S + 2 * k + 1]};  // the stage's group decides: wave-uniform
+                const f2 t = a * y[k];
+                r += t[0];
+                r += t[1];
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (L > 0) {
+#pragma unroll
+                for (int t = 0; t < L; t += 2) {
+                    const f2 a = {prep[gg * S + R + t], prep[gg * S + R + t + 1]};
+                    const f2 q = {tail[t][threadIdx.x], tail[t + 1][threadIdx.x]};
+                    const f2 p = a * q;
+                    r += p[0];
+                    r += p[1];
+                    if ((t & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // (else all L rows are read up front)
+                }
+            }
+        }
+    } else if (g == G - 1 && v0 < num_voxels) {
+        // A constant voxel (sd = 0) or a tiny mean somewhere in the wave: plain divisions.  The storing lanes redo pass 3
+        // from memory (the lines are still in L2), 16 or 8 members per step with their loads in flight together; y_e - meanY is
+        // recomputed from the same operands: the same float.  (A second unrolled body over y[] -- quotients in place, or
+        // taken on the fly per stage -- costs the whole kernel its register allocation: 0.9-2 KB of scratch per lane;
+        // in groups of 8 slots under a uniform branch still 150-320 B.)
+        constexpr int kStep = G == 2 ? 16 : 8;  // (16 live values cost the four-lane instantiations 0.1-0.4 KB of scratch)
+        int e = 0;
+#pragma unroll 1
+        for (; e + kStep <= cs; e += kStep) {
+            float v[kStep];
+#pragma unroll
+            for (int i = 0; i < kStep; i++) v[i] = load_member(members[e + i], byte_offset);
+#pragma unroll
+            for (int i = 0; i < kStep; i++) r += prep[e + i] * ((v[i] - meanY) / sdY);
+        }
+#pragma unroll 1
+        for (; e < cs; e++) r += prep[e] * ((load_member(members[e], byte_offset) - meanY) / sdY);
+    }
+    if (g == G - 1 && v0 < num_voxels) store_result_nt(out + v0, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -763,6 +1027,54 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
 
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
+    // 321..1216 members: two (up to 576) or four lanes per voxel (pearson_split_kernel).  CRF_PEARSON_SPLIT=0 selects the
+    // r02 kernels (VGPRs + AGPRs at one wave per SIMD up to 384 members, the 8-wave relay up to 512, three sweeps beyond).
+    if (cs > 320 && cs <= kSplitMaxMembers && env_int("CRF_PEARSON_SPLIT", 1) != 0) {
+        const int lanes = cs > 576 ? 4 : 2;  // (two lanes x 304 slots = 224 + 80 LDS rows: 0.5 KB of scratch per lane)
+        const int slots = ((cs + lanes - 1) / lanes + 15) / 16 * 16;  // per lane, in steps of 16: 160 .. 304
+        const size_t per_block = size_t(4) * (64 / lanes);
+        const size_t blocks_ = (num_voxels + per_block - 1) / per_block;
+        hipError_t attr = hipSuccess;
+        bool launched = false;
+#define CRF_LAUNCH_SPLIT(R_, L_, G_, W_)                                                                          \
+    {                                                                                                             \
+        constexpr size_t kBytes = size_t(L_) * 256 * sizeof(float);                                               \
+        const auto kern = &pearson_split_kernel<R_, L_, G_, 16 * G_, W_>;                                         \
+        if (kBytes > 64 * 1024)                                                                                   \
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(kBytes));                  \
+        if (attr == hipSuccess && blocks_ > 0)                                                                    \
+            hipLaunchKernelGGL(kern, dim3(unsigned(blocks_)), dim3(256), kBytes, s, d_members, d_prep, d_out,      \
+                               uint32_t(num_voxels), cs);                                                         \
+        launched = attr == hipSuccess;                                                                            \
+    }
+#define CRF_LAUNCH_SPLIT_G(R_, L_, W_)                                                                            \
+    if (lanes == 2) CRF_LAUNCH_SPLIT(R_, L_, 2, W_) else CRF_LAUNCH_SPLIT(R_, L_, 4, W_)
+        switch (slots) {
+            case 160: CRF_LAUNCH_SPLIT(160, 0, 4, 2); break;  // 577..640 members
+            case 176: CRF_LAUNCH_SPLIT_G(176, 0, 2); break;
+            case 192: CRF_LAUNCH_SPLIT_G(192, 0, 2); break;
+            case 208: CRF_LAUNCH_SPLIT_G(208, 0, 2); break;
+            // beyond 208 slots the rest goes to LDS rows: with 224 register slots the allocation is at its edge and
+            // whether 16 B or 0.5 KB of scratch come out depends on details of the rare path (measured: 448 members
+            // 72 % of the peak without, 63 % with 52 B of scratch)
+            case 224: CRF_LAUNCH_SPLIT_G(208, 16, 2); break;
+            case 240: CRF_LAUNCH_SPLIT_G(216, 24, 2); break;
+            case 256: CRF_LAUNCH_SPLIT_G(216, 40, 2); break;
+            case 272: CRF_LAUNCH_SPLIT_G(216, 56, 2); break;
+            case 288: CRF_LAUNCH_SPLIT_G(216, 72, 2); break;
+            case 304: CRF_LAUNCH_SPLIT(224, 80, 4, 2); break;  // 80 KB of LDS per block: still two blocks per CU
+            // (320 slots = 224 + 96 LDS rows: one block per CU, 17-32 % of the peak -- not instantiated)
+            default: break;
+        }
+#undef CRF_LAUNCH_SPLIT_G
+#undef CRF_LAUNCH_SPLIT
+        if (launched) {
+            covered = num_voxels;
+            if (info) info->kernel_name = "pearson_split_kernel";
+            goto tail;
+        }
+    }
     if (cs <= kMaxRegisterMembers) {
         const int cs_pad = cs <= 8 ? 8 : cs <= 128 ? (cs + 15) / 16 * 16 : cs <= 224 ? (cs + 31) / 32 * 32
                          : cs <= 240 ? 240 : cs <= 256 ? (cs + 7) / 8 * 8 : (cs + 63) / 64 * 64;

@@ -100,7 +100,63 @@ def test_pearson_device_path_matches_host_path(engine, oracle):
     assert bit_identical(out.cpu().numpy(), want).all()
 
 
-@pytest.mark.parametrize("cs", [16, 64, 100, 200, 400, 600])
+# pearson_split_kernel (two / four lanes per voxel): every instantiation's first and last member count, both lane counts
+@pytest.mark.parametrize("cs", [321, 322, 352, 353, 416, 417, 448, 449, 480, 481, 544, 545, 576, 607, 608, 609, 640,
+                                641, 642, 704, 705, 768, 769, 832, 896, 897, 960, 961, 1088, 1089, 1152, 1153, 1216, 1217,
+                                1279, 1280, 1281])
+def test_pearson_lanes_per_voxel_kernel_boundaries(engine, oracle, cs):
+    ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
+    got, want = _run(engine, oracle, ens, (7, 3, 2))
+    assert_bit_exact(got, want, f"pearson cs={cs}")
+    assert engine.last_kernel_name() == ("pearson_split_kernel" if 320 < cs <= 1216 else "pearson_big_kernel")
+
+
+@pytest.mark.parametrize("cs", [340, 500, 650, 1000])
+def test_pearson_lanes_per_voxel_kernel_edge_cases(engine, oracle, cs):
+    """NaN / inf members, constant voxels (sd = 0 -> the plain-division path of the whole wave), extreme magnitudes, in
+    every lane group's member range and in the last group's padded granule."""
+    rng = np.random.default_rng(cs)
+    ens = rng.standard_normal((cs, 3, 8, 32)).astype(np.float32)
+    ens[:, 0, 0, 1] = 0.0
+    ens[:, 0, 0, 4] = 3.25
+    for i, e in enumerate([0, cs // 4, cs // 2 - 1, cs // 2, 3 * cs // 4, cs - 2, cs - 1]):
+        ens[e, 1, 0, 2 * i] = np.nan
+        ens[e, 1, 1, 2 * i] = np.inf
+        ens[e, 1, 2, 2 * i] = -1e30
+    ens[:, 2, 1, 1] = ens[:, 2, 2, 2] * 1e-30
+    ens[:, 2, 1, 2] = ens[:, 2, 2, 2] * 1e18
+    got, want = _run(engine, oracle, ens, (2, 2, 2))
+    assert_bit_exact(got, want, f"pearson edge cases cs={cs}")
+    assert engine.last_kernel_name() == "pearson_split_kernel"
+
+
+@pytest.mark.parametrize("cs", [64, 340, 512, 700, 1000, 1200])
+def test_pearson_means_that_are_exactly_zero(engine, oracle, cs):
+    """Antithetic member pairs (y, -y) sum to a mean of exactly 0 in the reference's sequential fp32 pass, which fails the
+    |mean| >= 2^-70 test of the exact-division path (the benchmark's box ensemble has such voxels at 512 members).
+    pearson_split_kernel then looks at the deviations themselves: voxels of ordinary magnitude stay on the exact path,
+    voxels with deviations below 2^-100 (here: values around 1e-33 and 1e-38, denormals included) take plain divisions."""
+    rng = np.random.default_rng(cs)
+    xs, ys, zs = 64, 16, 4
+    n = xs * ys * zs
+    half = rng.standard_normal((cs // 2, n)).astype(np.float32)
+    scale = np.ones(n, np.float32)
+    scale[n // 4:n // 2] = 1e-33          # whole waves of tiny deviations
+    scale[n // 2::97] = 1e-38             # and isolated ones inside ordinary waves
+    half *= scale
+    ens = np.empty((cs, n), np.float32)
+    ens[0::2] = half
+    ens[1::2] = -half
+    # ordinary voxels in which ONE pair is tiny (1e-35 < 2^-100, and a denormal): sd passes the range test, the deviations don't
+    ens[0, n // 2 + 5::97], ens[1, n // 2 + 5::97] = 1e-35, -1e-35
+    ens[2, n // 2 + 6::97], ens[3, n // 2 + 6::97] = 1e-41, -1e-41
+    ens = ens.reshape(cs, zs, ys, xs)
+    got, want = _run(engine, oracle, ens, (3, 2, 3))    # a reference voxel of ordinary magnitude
+    assert_bit_exact(got, want, f"pearson zero means cs={cs}")
+    assert np.isfinite(want[: n // 4]).all() and not np.isfinite(want[n // 4:n // 2]).any()
+
+
+@pytest.mark.parametrize("cs", [16, 64, 100, 200, 400, 600, 700, 1100])
 def test_pearson_magnitude_sweep_bit_exact(engine, oracle, cs):
     """Every voxel gets its own scale and offset over 50 decades, so the per-voxel quotient (y - mean) / sd is taken at
     standard deviations and means on both sides of the exact-division guard (crf_device.h: sd in [2^-60, 2^60],
