@@ -25,7 +25,7 @@ def rows(pattern):
 
 def short(name):
     name = name.split("(")[0]
-    for key in ("pearson_reg_lds_kernel", "pearson_reg_kernel", "pearson_relay_kernel", "pearson_big_kernel",
+    for key in ("pearson_split_kernel", "pearson_reg_lds_kernel", "pearson_reg_kernel", "pearson_relay_kernel", "pearson_big_kernel",
                 "pearson_stream_kernel", "pearson_prep_kernel", "spearman_u32_kernel", "spearman_split_kernel", "kendall_split_kernel",
                 "spearman_prep_kernel", "kendall_prep_kernel", "spearman_kernel", "kendall_kernel", "mi_binned_kernel",
                 "kraskov_direct_kernel", "kraskov_sorted_kernel", "kraskov_prep_kernel", "mi_kraskov_kernel", "minmax_kernel",
