@@ -269,10 +269,12 @@ size_t direct_rank_workspace_bytes(int cs, size_t num_voxels, int measure) {
 }
 
 // MEASURE 1: Spearman (prep = float a_e), 2: Kendall (prep = int perm / gend / n1 with stride cs)
-template <int MEASURE>
+// LIST: the voxels are those of a todo list {count, voxel indices...} (the ones a sort-based kernel deferred: ties)
+template <int MEASURE, bool LIST = false>
 __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __restrict__ members,
                                                          const void* __restrict__ prep, float* __restrict__ out,
-                                                         size_t num_voxels, int cs, uint16_t* __restrict__ workspace) {
+                                                         size_t num_voxels, int cs, uint16_t* __restrict__ workspace,
+                                                         const uint32_t* __restrict__ todo) {
     constexpr int measure = MEASURE;
     constexpr int T = kDirectRows;
     const int lane = threadIdx.x;
@@ -280,10 +282,12 @@ __global__ __launch_bounds__(64) void direct_rank_kernel(const float* const* __r
     const int* prep_i = static_cast<const int*>(prep);
     const float* prep_a = static_cast<const float*>(prep);
     uint16_t* aux = workspace ? workspace + size_t(blockIdx.x) * size_t(cs) * 64 + lane : nullptr;
-    const size_t tiles = (num_voxels + 63) / 64;
+    const size_t listed = LIST ? size_t(todo[0]) : 0;
+    const size_t tiles = ((LIST ? listed : num_voxels) + 63) / 64;
 #pragma unroll 1
     for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const size_t v = t * 64 + lane;
+        size_t v = t * 64 + lane;
+        if constexpr (LIST) v = v < listed ? size_t(todo[1 + v]) : num_voxels;  // a lane past the end of the list: idle
         const uint32_t off = v < num_voxels ? uint32_t(v) * 4u : kOutOfRangeOffset;
         float res;
         bool is_nan = false;
@@ -926,7 +930,8 @@ hipError_t launch_pair_requests(const float* const* d_members_i, const float* co
 
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
-                          float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info) {
+                          float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info,
+                          uint32_t* d_todo) {
     switch (ref.prepare() ? a.measure : -1) {
         case -1: break;
         case 1: launch_spearman_prep(ref, d_members, cs, d_prep, s); break;
@@ -951,14 +956,26 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
         const unsigned dblocks = unsigned(tiles < size_t(kDirectBlocks) ? tiles : size_t(kDirectBlocks));
         if (a.measure == 1 && !d_workspace) return hipErrorInvalidValue;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
+        // Spearman at 129..256 members: two sorted chunks merged through LDS (kernels_rank.hip: spearman_pair_kernel),
+        // then this file's counting kernel over the voxels it deferred (ties).  CRF_RANK_PAIR=0: counting kernel for all.
+        const char* pair_env = getenv("CRF_RANK_PAIR");
+        if (a.measure == 1 && !(pair_env && *pair_env == '0') &&
+            launch_spearman_pair(d_members, d_prep, d_out, num_voxels, cs, d_todo, s)) {
+            hipLaunchKernelGGL((direct_rank_kernel<1, true>), dim3(dblocks < 1024u ? dblocks : 1024u), dim3(64), 0, s,
+                               d_members, static_cast<const void*>(d_prep), d_out, num_voxels, cs,
+                               reinterpret_cast<uint16_t*>(d_workspace), static_cast<const uint32_t*>(d_todo));
+            if (ev_end) (void)hipEventRecord(ev_end, s);
+            if (info) info->kernel_name = "spearman_pair_kernel";
+            return hipGetLastError();
+        }
         if (a.measure == 1)
-            hipLaunchKernelGGL(direct_rank_kernel<1>, dim3(dblocks), dim3(64), 0, s, d_members,
+            hipLaunchKernelGGL((direct_rank_kernel<1, false>), dim3(dblocks), dim3(64), 0, s, d_members,
                                static_cast<const void*>(d_prep), d_out, num_voxels, cs,
-                               reinterpret_cast<uint16_t*>(d_workspace));
+                               reinterpret_cast<uint16_t*>(d_workspace), static_cast<const uint32_t*>(nullptr));
         else
-            hipLaunchKernelGGL(direct_rank_kernel<2>, dim3(dblocks), dim3(64), 0, s, d_members,
+            hipLaunchKernelGGL((direct_rank_kernel<2, false>), dim3(dblocks), dim3(64), 0, s, d_members,
                                static_cast<const void*>(d_prep), d_out, num_voxels, cs,
-                               reinterpret_cast<uint16_t*>(d_workspace));
+                               reinterpret_cast<uint16_t*>(d_workspace), static_cast<const uint32_t*>(nullptr));
         if (ev_end) (void)hipEventRecord(ev_end, s);
         if (info) info->kernel_name = "direct_rank_kernel";
         return hipGetLastError();

@@ -717,6 +717,257 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 129..256 members (r03): TWO chunks of N <= 128 members, each sorted like spearman_u32_kernel sorts its one (u32
+// composites, one register network, close pairs put right from the dropped bits), merged through LDS.  Before this the
+// step from 128 to 129 members was a step to the O(cs^2) counting kernel (256^3: 3.1 -> 46 ms; 164 ms at 256 members).
+//   chunk A = members [0, N): sorted, composites to the lane's LDS column comp_a;
+//   chunk B = members [N, cs): sorted in registers; every element looks up how many of A lie below it (branch-free binary
+//     search in comp_a on the upper 25 key bits, 8 elements per step so that 8 LDS reads are in flight; an A element
+//     with the same upper bits is ordered from the dropped bits, a second one or a true tie defers the voxel);
+//     rank - 1 of B's q-th element = q + that count, and a histogram over the counts gives the A side by a prefix sum:
+//     #{B below A[p]} = #{q : count_q <= p};
+//   ranks go to LDS by member (over the dropped bits, which are dead by then) and the fp32 tail -- computePearson2<float>
+//   over the ranks in member order -- streams them from there in rolled loops.
+// LDS per wave: 448 N + 512 bytes (N = 128: 57 KB, two waves per CU; N = 72: 32 KB, four).
+// Voxels with ties (fractional ranks) or three keys within 2^-16 relative go through the todo list to the counting
+// kernel (direct_rank_kernel, LIST form), as in the narrower kernels.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, int SURE>
+__device__ __forceinline__ void sort_chunk_u32(const float* const* __restrict__ members, int first, int cs, uint32_t bytes,
+                                               uint32_t byte_offset, uint8_t* __restrict__ low_col, uint32_t (&a)[N],
+                                               bool& is_nan, bool& defer) {
+    uint32_t key_min = 0xFFFFFFFFu, key_max = 0u;
+#pragma unroll
+    for (int e = 0; e < N; e++) {  // all loads first (slots past cs: out-of-range offset, no memory request)
+        const bool real = e < SURE || first + e < cs;
+        a[e] = __float_as_uint(
+            load_member_nt(members[real ? first + e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset));
+    }
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        const float yc = __uint_as_float(a[e]) + 0.0f;  // -0.0 -> +0.0: key equality is float equality
+        const bool real = e < SURE || first + e < cs;
+        const uint32_t okey = orderable_key(yc);
+        key_min = min(key_min, okey);
+        key_max = max(key_max, real ? okey : 0u);
+        const uint32_t key = real ? okey : 0xFFFFFFFFu;  // pads sort last
+        low_col[e * 64] = uint8_t(key & 0x7Fu);
+        a[e] = (key & ~0x7Fu) | uint32_t(e);
+        if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // pinned here (see spearman_u32_kernel)
+        uint32_t nan_flag = keys_hold_nan(key_min, key_max) ? 1u : 0u;
+        asm volatile("" : "+v"(nan_flag));
+        is_nan |= nan_flag != 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SortNet32<N>::sort(a);
+    pin_array(a);
+    __builtin_amdgcn_sched_barrier(0);
+    bool prev_close = false;
+#pragma unroll
+    for (int q = 0; q + 1 < N; q++) {
+        const bool both_real = q + 1 < SURE || first + q + 1 < cs;
+        const bool close = both_real && ((a[q] ^ a[q + 1]) < 128u);
+        if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
+            asm volatile("" ::: "memory");              // a real branch (see spearman_u32_kernel)
+            if (close) {
+                const uint32_t la = low_col[(a[q] & 0x7Fu) * 64], lb = low_col[(a[q + 1] & 0x7Fu) * 64];
+                defer |= (la == lb) | prev_close;
+                if (la > lb) {
+                    const uint32_t t = a[q];
+                    a[q] = a[q + 1];
+                    a[q + 1] = t;
+                }
+            }
+        }
+        prev_close = close;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pin_array(a);
+}
+
+template <int N, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const float* const* __restrict__ members,
+                                                                      const float* __restrict__ prep,
+                                                                      float* __restrict__ out, size_t num_voxels, int cs,
+                                                                      uint32_t* __restrict__ todo) {
+    static_assert(N <= 128 && N % 8 == 0 && N >= 72, "two chunks of N members, slots are 7 bits");
+    __shared__ uint32_t comp_a[N * 64];      // [position][lane]: chunk A's sorted composites
+    __shared__ uint8_t low_of[2 * N * 64];   // [member][lane]: dropped key bits; after the merge: rank - 1
+    __shared__ uint8_t hist[(N + 8) * 64];   // [count][lane], count = 0..N: marks (see the merge)
+    constexpr int TOP = N == 128 ? 128 : 64;  // largest power of two <= N
+    constexpr int G = N % 16 == 0 ? 16 : 8;    // B elements whose searches run together (their LDS reads are in flight together)
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const bool active = v < num_voxels;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    bool is_nan = false, defer = false;
+    uint32_t a[N];
+    // ---- chunk A = members [0, N) (all of them members: cs > 2 N - 16 >= N), then chunk B = members [N, 2 N), whose last
+    //      16 slots may be padding.  ONE copy of the loads / keys / network / close-pair code runs twice (a rolled loop):
+    //      the kernel is straight-line code far beyond the instruction cache and is paced by instruction fetch.
+#pragma unroll 1
+    for (int chunk = 0; chunk < 2; chunk++) {
+        sort_chunk_u32<N, N - 16>(members, chunk * N, cs, bytes, byte_offset, low_of + chunk * N * 64 + lane, a, is_nan,
+                                  defer);
+        if (chunk == 0) {
+#pragma unroll
+            for (int q = 0; q < N; q++) comp_a[q * 64 + lane] = a[q];
+            for (int i = lane; i < (N + 8) * 16; i += 64) reinterpret_cast<uint32_t*>(hist)[i] = 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // one wave per block: orders the cooperative clearing of hist above before its use
+    const int nb = cs - N;  // chunk B's members sit at the sorted positions [0, nb): pads sort last
+    // (This file is compiled in source order, -enable-misched=0: every group of LDS reads below is written out before
+    // the first use of any of them, so that the reads of a group are in flight together.)
+    // ---- every B element: how many of A lie below it
+#pragma unroll
+    for (int q0 = 0; q0 < N; q0 += G) {
+        if (q0 < N - 16 || q0 < nb) {  // uniform: a group of pads only
+            uint32_t up[G], pos[G], val[G];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                up[u] = a[q0 + u] & ~0x7Fu;
+                pos[u] = 0u;
+            }
+            // (up's slot bits are 0, so composite < up  <=>  upper bits < up: no masking of the probed value)
+            if constexpr (N == 128) {  // a power of two: lower bound by halving, no index ever leaves the column
+#pragma unroll
+                for (int half = 64; half >= 1; half >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < G; u++) val[u] = comp_a[(pos[u] + uint32_t(half - 1)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < G; u++) pos[u] = val[u] < up[u] ? pos[u] + uint32_t(half) : pos[u];
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++) val[u] = comp_a[pos[u] * 64 + lane];  // pos <= 127 here
+#pragma unroll
+                for (int u = 0; u < G; u++) pos[u] = val[u] < up[u] ? pos[u] + 1u : pos[u];
+            } else {
+#pragma unroll
+                for (int step = TOP; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        const uint32_t idx = pos[u] + uint32_t(step);
+                        val[u] = comp_a[((idx <= uint32_t(N) ? idx : uint32_t(N)) - 1u) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        const uint32_t idx = pos[u] + uint32_t(step);
+                        pos[u] = (idx <= uint32_t(N) && val[u] < up[u]) ? idx : pos[u];
+                    }
+                }
+            }
+            // the A element at that position, if its upper bits are the same: order by the dropped bits
+#pragma unroll
+            for (int u = 0; u < G; u++) val[u] = comp_a[(pos[u] < uint32_t(N) ? pos[u] : uint32_t(N - 1)) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int q = q0 + u;
+                const bool real = q < N - 16 || q < nb;
+                const bool close = real && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
+                if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
+                    asm volatile("" ::: "memory");
+                    if (close) {
+                        const uint32_t la = low_of[(val[u] & 0x7Fu) * 64 + lane];
+                        const uint32_t lb = low_of[(N + (a[q] & 0x7Fu)) * 64 + lane];
+                        bool more = false;  // a second A element with these upper bits
+                        if (pos[u] + 1u < uint32_t(N)) more = ((comp_a[(pos[u] + 1u) * 64 + lane] ^ a[q]) < 128u);
+                        defer |= (la == lb) | more;
+                        if (la < lb) pos[u] += 1u;
+                    }
+                }
+                if (real) {
+                    // the counts ascend with q: the last q that leaves its mark at a count is the number of B elements
+                    // with at most that count, minus one (writes only: no read-modify-write chain through LDS)
+                    hist[pos[u] * 64 + lane] = uint8_t(q + 1);
+                    a[q] = ((uint32_t(q) + pos[u]) << 7) | (a[q] & 0x7Fu);  // rank - 1, slot
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- ranks by member: A from the running maximum of the marks, B from the registers
+    {
+        uint32_t below = 0u;  // B elements below A[p] = #{q : count_q <= p}
+#pragma unroll
+        for (int p0 = 0; p0 < N; p0 += 8) {
+            uint32_t h[8], ca[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) h[u] = hist[(p0 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ca[u] = comp_a[(p0 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                below = max(below, h[u]);
+                low_of[(ca[u] & 0x7Fu) * 64 + lane] = uint8_t(uint32_t(p0 + u) + below);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            if (q < N - 16 || q < nb) low_of[(N + (a[q] & 0x7Fu)) * 64 + lane] = uint8_t(a[q] >> 7);
+            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- computePearson2<float>(referenceRanks, ranks, cs) in member order (Correlation.cpp:141-174), ranks from LDS,
+    //      16 at a time (a rank past cs reads as whatever the column holds and is not used)
+    const uint8_t* rank_col = low_of + lane;
+    const float n = float(cs);
+    const float invN = 1.0f / n;
+    const float invNm1 = 1.0f / (n - 1.0f);
+    float meanY = 0.0f;
+#pragma unroll 1
+    for (int e0 = 0; e0 < cs; e0 += 16) {
+        uint32_t rk[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (e0 + u < cs) meanY += invN * float(rk[u] + 1u);
+    }
+    float varY = 0.0f;
+#pragma unroll 1
+    for (int e0 = 0; e0 < cs; e0 += 16) {
+        uint32_t rk[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float d = float(rk[u] + 1u) - meanY;
+            if (e0 + u < cs) varY += invNm1 * d * d;
+        }
+    }
+    const float sdY = sqrtf(varY);
+    float res = 0.0f;
+    if (__all(exact_div_guard(meanY, sdY))) {
+        const float rcp = 1.0f / sdY;
+#pragma unroll 1
+        for (int e0 = 0; e0 < cs; e0 += 16) {
+            uint32_t rk[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (e0 + u < cs) res += prep[e0 + u] * exact_div(float(rk[u] + 1u) - meanY, sdY, rcp);
+        }
+    } else {
+#pragma unroll 4
+        for (int e = 0; e < cs; e++) res += prep[e] * ((float(uint32_t(rank_col[e * 64]) + 1u) - meanY) / sdY);
+    }
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (active) {
+        if (defer && !is_nan) {
+            todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        } else {
+            store_result_nt(out + v, res);
+        }
+    }
+}
+
 // discordant pairs inside one sorted chunk: inversions of the slot sequence (slots 0..CH-1), one 64-bit "seen" set
 template <int CH, int SURE = 0>
 __device__ __forceinline__ int32_t chunk_inversions(const composite_t (&a)[CH], int count, bool exact) {
@@ -945,6 +1196,34 @@ int env_waves(int fallback) {
 }
 
 }  // namespace
+
+// 129..256 members: spearman_pair_kernel; the caller runs the counting kernel over d_todo afterwards (voxels with ties).
+bool launch_spearman_pair(const float* const* d_members, const float* d_prep, float* d_out, size_t num_voxels, int cs,
+                          uint32_t* d_todo, hipStream_t s) {
+    if (cs <= 128 || cs > 256 || !d_todo) return false;
+    (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    const int n = ((cs + 1) / 2 + 7) / 8 * 8;  // chunk size: 2 n - 16 < cs <= 2 n
+#define CRF_LAUNCH_PAIR(NN)                                                                                             \
+    case NN:                                                                                                            \
+        hipLaunchKernelGGL((spearman_pair_kernel<NN, (NN > 112 ? 1 : 2)>), dim3(blocks), dim3(64), 0, s, d_members,     \
+                           d_prep, d_out,                                                                               \
+                           num_voxels, cs, d_todo);                                                                     \
+        break
+    switch (n) {
+        CRF_LAUNCH_PAIR(72);
+        CRF_LAUNCH_PAIR(80);
+        CRF_LAUNCH_PAIR(88);
+        CRF_LAUNCH_PAIR(96);
+        CRF_LAUNCH_PAIR(104);
+        CRF_LAUNCH_PAIR(112);
+        CRF_LAUNCH_PAIR(120);
+        CRF_LAUNCH_PAIR(128);
+        default: return false;
+    }
+#undef CRF_LAUNCH_PAIR
+    return true;
+}
 
 void launch_spearman_prep(const RefSource& ref, const float* const* d_members, int cs, float* d_prep, hipStream_t s) {
     hipLaunchKernelGGL(spearman_prep_kernel, dim3(1), dim3(256), size_t(2 * cs) * sizeof(float), s, ref, d_members, cs,

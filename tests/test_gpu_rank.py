@@ -116,15 +116,7 @@ def test_rank_64cubed_16_members(engine, oracle, measure, omeasure):
     _check(engine, oracle, ens, (8, 8, 32), measure, omeasure, f"{measure.name} 64^3x16")
 
 
-@pytest.mark.parametrize("u32", ["0", "1"])
-@pytest.mark.parametrize("cs", [33, 40, 47, 48, 56, 63, 64, 65, 72, 73, 80, 81, 95, 96, 100, 104, 111, 120, 127, 128])
-def test_spearman_values_that_agree_in_their_upper_bits(engine, oracle, monkeypatch, cs, u32):
-    """The 33..128-member Spearman kernel sorts 32-bit composites that carry only the upper 25 bits of a member's key;
-    members whose values agree in those bits are put in order from the dropped bits afterwards, runs of three and exact
-    ties go to the exact kernel.  Voxels full of such values: pairs one / a few ulps apart (positive, negative, across
-    zero, denormals), runs of three and four close values, close values next to exact ties, a NaN, +-inf, the largest
-    and smallest members affected.  Both kernels forced (CRF_RANK_U32 = 0: split-sort, 1: u32 network)."""
-    monkeypatch.setenv("CRF_RANK_U32", u32)
+def _ensemble_of_close_values(cs):
     rng = np.random.default_rng(1000 + cs)
     xs, ys, zs = 16, 8, 4
     ens = rng.standard_normal((cs, zs, ys, xs)).astype(np.float32)
@@ -167,7 +159,48 @@ def test_spearman_values_that_agree_in_their_upper_bits(engine, oracle, monkeypa
         else:              # a NaN voxel with close pairs in it
             flat[members[1], vox] = ulps(base, 1)
             flat[members[2], vox] = np.nan
+    return ens
+
+
+@pytest.mark.parametrize("u32", ["0", "1"])
+@pytest.mark.parametrize("cs", [33, 40, 47, 48, 56, 63, 64, 65, 72, 73, 80, 81, 95, 96, 100, 104, 111, 120, 127, 128])
+def test_spearman_values_that_agree_in_their_upper_bits(engine, oracle, monkeypatch, cs, u32):
+    """The 33..128-member Spearman kernel sorts 32-bit composites that carry only the upper 25 bits of a member's key;
+    members whose values agree in those bits are put in order from the dropped bits afterwards, runs of three and exact
+    ties go to the exact kernel.  Voxels full of such values: pairs one / a few ulps apart (positive, negative, across
+    zero, denormals), runs of three and four close values, close values next to exact ties, a NaN, +-inf, the largest
+    and smallest members affected.  Both kernels forced (CRF_RANK_U32 = 0: split-sort, 1: u32 network)."""
+    monkeypatch.setenv("CRF_RANK_U32", u32)
+    ens = _ensemble_of_close_values(cs)
     ref_xyz = (1, 0, 0)                                  # voxel 1: untouched by the loop above
     _check(engine, oracle, ens, ref_xyz, Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman close values cs={cs} u32={u32}")
     expect = "spearman_u32_kernel" if u32 == "1" else ("spearman_kernel" if cs == 64 else "spearman_split_kernel")
     assert engine.last_kernel_name() == expect
+
+
+PAIR_COUNTS = [129, 130, 143, 144, 145, 159, 160, 161, 176, 177, 192, 193, 208, 209, 224, 225, 239, 240, 241, 255, 256]
+
+
+@pytest.mark.parametrize("pair", ["1", "0"])
+@pytest.mark.parametrize("cs", PAIR_COUNTS)
+def test_spearman_129_to_256_members_close_values(engine, oracle, monkeypatch, cs, pair):
+    """129..256 members: two sorted chunks of 32-bit composites merged through LDS (spearman_pair_kernel); values that agree
+    in their upper key bits inside a chunk AND across the chunks, runs of three / four, exact ties, NaN, +-inf -- the same
+    voxels as above.  CRF_RANK_PAIR=0: the counting kernel for every voxel."""
+    monkeypatch.setenv("CRF_RANK_PAIR", pair)
+    ens = _ensemble_of_close_values(cs)
+    _check(engine, oracle, ens, (1, 0, 0), Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman close values cs={cs} pair={pair}")
+    assert engine.last_kernel_name() == ("spearman_pair_kernel" if pair == "1" else "direct_rank_kernel")
+
+
+@pytest.mark.parametrize("cs", [129, 150, 200, 256, 257])
+def test_spearman_129_to_256_members_box_ensemble_and_ties(engine, oracle, cs):
+    """The benchmark's box ensemble (plateaus: whole voxels of exact ties -> the deferred-voxel list), a grid that is not a
+    multiple of 64 voxels, rounded values (ties everywhere), a separate reference vector with ties."""
+    ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
+    ens[:, 0, 0, :] = np.round(ens[:, 0, 0, :] * 4)
+    ens[7, 1, 1, 1] = np.nan
+    _check(engine, oracle, ens, (5, 6, 4), Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman box ensemble cs={cs}")
+    assert engine.last_kernel_name() == ("spearman_pair_kernel" if cs <= 256 else "direct_rank_kernel")
+    _check(engine, oracle, ens, None, Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman tied reference cs={cs}",
+           reference_values=np.round(ens[:, 3, 3, 3] * 3))
