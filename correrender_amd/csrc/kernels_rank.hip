@@ -729,7 +729,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
 //     #{B below A[p]} = #{q : count_q <= p};
 //   ranks go to LDS by member (over the dropped bits, which are dead by then) and the fp32 tail -- computePearson2<float>
 //   over the ranks in member order -- streams them from there in rolled loops.
-// LDS per wave: 448 N + 512 bytes (N = 128: 57 KB, two waves per CU; N = 72: 32 KB, four).
+// LDS per wave: 384 N + 512 bytes (N = 128: 49 KB, three waves per CU; N = 72: 28 KB, five).
 // Voxels with ties (fractional ranks) or three keys within 2^-16 relative go through the todo list to the counting
 // kernel (direct_rank_kernel, LIST form), as in the narrower kernels.
 // ---------------------------------------------------------------------------------------------------------------
@@ -794,9 +794,10 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
                                                                       float* __restrict__ out, size_t num_voxels, int cs,
                                                                       uint32_t* __restrict__ todo) {
     static_assert(N <= 128 && N % 8 == 0 && N >= 72, "two chunks of N members, slots are 7 bits");
-    __shared__ uint32_t comp_a[N * 64];      // [position][lane]: chunk A's sorted composites
-    __shared__ uint8_t low_of[2 * N * 64];   // [member][lane]: dropped key bits; after the merge: rank - 1
-    __shared__ uint8_t hist[(N + 8) * 64];   // [count][lane], count = 0..N: marks (see the merge)
+    __shared__ uint32_t comp_a[N * 64];          // [position][lane]: chunk A's sorted composites
+    __shared__ uint8_t low_of[(2 * N + 8) * 64];  // [member][lane]: dropped key bits; after the searches rows [N, 2N] hold
+                                                  // the marks (see below), and in the end all rows hold rank - 1 by member
+    uint8_t* const hist = low_of + N * 64;        // [count][lane], count = 0..N
     constexpr int TOP = N == 128 ? 128 : 64;  // largest power of two <= N
     constexpr int G = N % 16 == 0 ? 16 : 8;    // B elements whose searches run together (their LDS reads are in flight together)
     const int lane = threadIdx.x;
@@ -815,11 +816,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
         if (chunk == 0) {
 #pragma unroll
             for (int q = 0; q < N; q++) comp_a[q * 64 + lane] = a[q];
-            for (int i = lane; i < (N + 8) * 16; i += 64) reinterpret_cast<uint32_t*>(hist)[i] = 0u;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();  // one wave per block: orders the cooperative clearing of hist above before its use
     const int nb = cs - N;  // chunk B's members sit at the sorted positions [0, nb): pads sort last
     // (This file is compiled in source order, -enable-misched=0: every group of LDS reads below is written out before
     // the first use of any of them, so that the reads of a group are in flight together.)
@@ -880,15 +879,20 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
                         if (la < lb) pos[u] += 1u;
                     }
                 }
-                if (real) {
-                    // the counts ascend with q: the last q that leaves its mark at a count is the number of B elements
-                    // with at most that count, minus one (writes only: no read-modify-write chain through LDS)
-                    hist[pos[u] * 64 + lane] = uint8_t(q + 1);
-                    a[q] = ((uint32_t(q) + pos[u]) << 7) | (a[q] & 0x7Fu);  // rank - 1, slot
-                }
+                if (real) a[q] = ((uint32_t(q) + pos[u]) << 7) | (a[q] & 0x7Fu);  // rank - 1, slot
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the dropped bits are dead now: their B half becomes the marks.  The counts ascend with q, so the last q that
+    //      leaves its mark at a count is the number of B elements with at most that count, minus one (writes only: no
+    //      read-modify-write chain through LDS), and #{B below A[p]} = #{q : count_q <= p} is a running maximum.
+    for (int i = lane; i < (N + 8) * 16; i += 64) reinterpret_cast<uint32_t*>(hist)[i] = 0u;
+    __syncthreads();  // one wave per block: orders the cooperative clearing before the marks
+#pragma unroll
+    for (int q = 0; q < N; q++) {
+        if (q < N - 16 || q < nb) hist[((a[q] >> 7) - uint32_t(q)) * 64 + lane] = uint8_t(q + 1);
+        if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- ranks by member: A from the running maximum of the marks, B from the registers
     {
