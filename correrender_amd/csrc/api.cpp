@@ -831,10 +831,11 @@ static int compute_impl_one(crf_context* c, const crf_params* p, const void* dev
         crf::GenericArgs ga{p->measure, p->num_bins, p->min_ref, p->max_ref, p->min_query, p->max_query, p->k,
                             p->kraskov_estimator_index == 2 ? 2 : 1,
                             kraskov_c_term(p->k > 0 ? p->k : 1, p->kraskov_estimator_index == 2 ? 2 : 1)};
-        if (p->measure == CRF_SPEARMAN && c->cs <= 256 && !c->d_todo)  // the sort-based kernel's list of deferred voxels
+        const bool rank_measure = p->measure == CRF_SPEARMAN || p->measure == CRF_KENDALL;
+        if (rank_measure && c->cs <= 256 && !c->d_todo)  // the sort-based kernels' list of deferred voxels
             CRF_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_todo), (c->alloc_voxels + 1) * sizeof(uint32_t)));
         e = crf::launch_generic(c->d_member_table, c->cs, c->num_voxels, ref, ga, c->d_tables, prep, c->d_workspace,
-                                out, s, e0, e1, &info, p->measure == CRF_SPEARMAN ? c->d_todo : nullptr);
+                                out, s, e0, e1, &info, rank_measure ? c->d_todo : nullptr);
         c->last_kernel = info.kernel_name ? info.kernel_name : "";
         if (e0 && e1) c->ev_pending.emplace_back(e0, e1);
         if (e != hipSuccess) return fail(c, CRF_ERR_DEVICE, fmt("kernel launch failed: %s", hipGetErrorString(e)));

@@ -123,7 +123,7 @@ struct GenericArgs {
 };
 // workspace: generic_workspace_bytes(cs, num_voxels) bytes of device memory (per-block voxel tiles)
 size_t generic_workspace_bytes(int cs, size_t num_voxels);
-// d_todo: num_voxels + 1 uint32, or null (Spearman at 129..256 members defers voxels with ties through it)
+// d_todo: num_voxels + 1 uint32, or null (Spearman / Kendall at 129..256 members defer voxels with ties through it)
 hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxels, const RefSource& ref,
                           const GenericArgs& a, const double* d_tables, float* d_prep, unsigned char* d_workspace,
                           float* d_out, hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info,
@@ -132,6 +132,8 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
 // counting kernel over d_todo afterwards.
 bool launch_spearman_pair(const float* const* d_members, const float* d_prep, float* d_out, size_t num_voxels, int cs,
                           uint32_t* d_todo, hipStream_t s);
+bool launch_kendall_pair(const float* const* d_members, const int* d_prep, float* d_out, size_t num_voxels, int cs,
+                         uint32_t* d_todo, hipStream_t s);
 // ---- kernels_stats.hip: ensemble mean (kind 0) / spread (kind 1) ------------------------------------------
 hipError_t launch_ensemble_stat(int kind, const float* const* d_members, int cs, size_t num_voxels, float* d_out,
                                 hipStream_t s, hipEvent_t ev_begin, hipEvent_t ev_end, LaunchInfo* info);

@@ -957,7 +957,8 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
         if (a.measure == 1 && !d_workspace) return hipErrorInvalidValue;
         if (ev_begin) (void)hipEventRecord(ev_begin, s);
         // Spearman at 129..256 members: two sorted chunks merged through LDS (kernels_rank.hip: spearman_pair_kernel),
-        // then this file's counting kernel over the voxels it deferred (ties).  CRF_RANK_PAIR=0: counting kernel for all.
+        // then this file's counting kernel over the voxels it deferred (ties); Kendall the same (kendall_pair_kernel).
+        // CRF_RANK_PAIR=0: counting kernel for all.
         const char* pair_env = getenv("CRF_RANK_PAIR");
         if (a.measure == 1 && !(pair_env && *pair_env == '0') &&
             launch_spearman_pair(d_members, d_prep, d_out, num_voxels, cs, d_todo, s)) {
@@ -966,6 +967,15 @@ hipError_t launch_generic(const float* const* d_members, int cs, size_t num_voxe
                                reinterpret_cast<uint16_t*>(d_workspace), static_cast<const uint32_t*>(d_todo));
             if (ev_end) (void)hipEventRecord(ev_end, s);
             if (info) info->kernel_name = "spearman_pair_kernel";
+            return hipGetLastError();
+        }
+        if (a.measure == 2 && !(pair_env && *pair_env == '0') &&
+            launch_kendall_pair(d_members, reinterpret_cast<const int*>(d_prep), d_out, num_voxels, cs, d_todo, s)) {
+            hipLaunchKernelGGL((direct_rank_kernel<2, true>), dim3(dblocks < 1024u ? dblocks : 1024u), dim3(64), 0, s,
+                               d_members, static_cast<const void*>(d_prep), d_out, num_voxels, cs,
+                               reinterpret_cast<uint16_t*>(d_workspace), static_cast<const uint32_t*>(d_todo));
+            if (ev_end) (void)hipEventRecord(ev_end, s);
+            if (info) info->kernel_name = "kendall_pair_kernel";
             return hipGetLastError();
         }
         if (a.measure == 1)

@@ -733,16 +733,18 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
 // Voxels with ties (fractional ranks) or three keys within 2^-16 relative go through the todo list to the counting
 // kernel (direct_rank_kernel, LIST form), as in the narrower kernels.
 // ---------------------------------------------------------------------------------------------------------------
+// perm: null = slot e of the chunk is member first + e; else member perm[first + e] (Kendall: reference-sorted order)
 template <int N, int SURE>
 __device__ __forceinline__ void sort_chunk_u32(const float* const* __restrict__ members, int first, int cs, uint32_t bytes,
                                                uint32_t byte_offset, uint8_t* __restrict__ low_col, uint32_t (&a)[N],
-                                               bool& is_nan, bool& defer) {
+                                               bool& is_nan, bool& defer, const int* __restrict__ perm = nullptr) {
     uint32_t key_min = 0xFFFFFFFFu, key_max = 0u;
 #pragma unroll
     for (int e = 0; e < N; e++) {  // all loads first (slots past cs: out-of-range offset, no memory request)
         const bool real = e < SURE || first + e < cs;
+        const int idx = real ? first + e : cs - 1;
         a[e] = __float_as_uint(
-            load_member_nt(members[real ? first + e : cs - 1], bytes, real ? byte_offset : kOutOfRangeOffset));
+            load_member_nt(members[perm ? perm[idx] : idx], bytes, real ? byte_offset : kOutOfRangeOffset));
     }
 #pragma unroll
     for (int e = 0; e < N; e++) {
@@ -962,6 +964,166 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
 #pragma unroll 4
         for (int e = 0; e < cs; e++) res += prep[e] * ((float(uint32_t(rank_col[e * 64]) + 1u) - meanY) / sdY);
     }
+    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (active) {
+        if (defer && !is_nan) {
+            todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
+        } else {
+            store_result_nt(out + v, res);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kendall at 129..256 members (r03), on the same two sorted chunks as spearman_pair_kernel.  Members are taken in
+// reference-sorted order (slot = position in the x order, kendall_prep_kernel), chunk A = the first N positions, chunk B the
+// rest, each sorted by y.  Discordant pairs (x_i < x_j beyond i's x-tie group, y_i > y_j) =
+//   inversions of the slot sequence inside A + inside B (a 128-bit "seen" set per lane: walking a chunk in ascending y,
+//   an element is discordant with every seen slot above its x-tie group's end)
+//   + for every B element the A elements above it in y: N - #{A below it}, the count the merge search yields.
+// Voxels with y ties or three close keys are deferred to the counting kernel (n2 = 0 for the others).  An x-tie group
+// that straddles the chunk boundary (its pairs would have to be taken out of the cross term) defers every voxel: the
+// reference vector decides, once per evaluation, and it is rare.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ int32_t chunk_inversions_u32(const uint32_t (&a)[N], const uint8_t* __restrict__ gend_tab,
+                                                        int first, int cs) {
+    uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;  // seen slots 0..127
+    int32_t inv = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < N; q0 += 8) {
+        uint32_t ge[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) ge[u] = gend_tab[a[q0 + u] & 0x7Fu];  // reads first (source order is the schedule)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u;
+            if (q < N - 16 || first + q < cs) {  // pads sort last: positions past the chunk's members
+                const uint32_t s = a[q] & 0x7Fu;
+                const uint32_t wi = ge[u] >> 5, sh = ge[u] & 31u;
+                const uint32_t sel = wi == 0u ? w0 : wi == 1u ? w1 : wi == 2u ? w2 : w3;
+                uint32_t c = __builtin_popcount((sel >> sh) >> 1);  // seen slots above the group's end, same word
+                c += wi < 1u ? __builtin_popcount(w1) : 0u;
+                c += wi < 2u ? __builtin_popcount(w2) : 0u;
+                c += wi < 3u ? __builtin_popcount(w3) : 0u;
+                inv += int32_t(c);
+                const uint32_t ws = s >> 5, bit = 1u << (s & 31u);
+                w0 |= ws == 0u ? bit : 0u;
+                w1 |= ws == 1u ? bit : 0u;
+                w2 |= ws == 2u ? bit : 0u;
+                w3 |= ws == 3u ? bit : 0u;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return inv;
+}
+
+template <int N, int MIN_WAVES>
+__global__ __launch_bounds__(64, MIN_WAVES) void kendall_pair_kernel(const float* const* __restrict__ members,
+                                                                     const int* __restrict__ prep,
+                                                                     float* __restrict__ out, size_t num_voxels, int cs,
+                                                                     uint32_t* __restrict__ todo) {
+    static_assert(N <= 128 && N % 8 == 0 && N >= 72, "two chunks of N slots, 7 slot bits");
+    __shared__ uint32_t comp_a[N * 64];     // [position][lane]: chunk A's sorted composites
+    __shared__ uint8_t low_of[2 * N * 64];  // [slot][lane]: dropped key bits
+    __shared__ uint8_t gend_tab[2 * N];     // per chunk: slot -> end of its x-tie group, as a slot of the chunk
+    constexpr int TOP = N == 128 ? 128 : 64;
+    constexpr int G = N % 16 == 0 ? 16 : 8;
+    const int lane = threadIdx.x;
+    const size_t v = size_t(blockIdx.x) * 64 + lane;
+    const bool active = v < num_voxels;
+    const uint32_t byte_offset = uint32_t(v) * 4u, bytes = uint32_t(num_voxels) * 4u;
+    const int* gend = prep + cs;
+    for (int i = lane; i < 2 * N; i += 64) {
+        const int first = i < N ? 0 : N;
+        const int g = i < cs ? gend[i] - first : N - 1;
+        gend_tab[i] = uint8_t(g < N - 1 ? g : N - 1);
+    }
+    bool is_nan = false;
+    bool defer = gend[N - 1] >= N;  // an x-tie group across the chunk boundary: the counting kernel for every voxel
+    __syncthreads();
+    uint32_t a[N];
+    int32_t discordant = 0;
+#pragma unroll 1
+    for (int chunk = 0; chunk < 2; chunk++) {  // one copy of the sort and of the inversion walk, run twice
+        sort_chunk_u32<N, N - 16>(members, chunk * N, cs, bytes, byte_offset, low_of + chunk * N * 64 + lane, a, is_nan,
+                                  defer, prep);
+        discordant += chunk_inversions_u32<N>(a, gend_tab + chunk * N, chunk * N, cs);
+        if (chunk == 0) {
+#pragma unroll
+            for (int q = 0; q < N; q++) comp_a[q * 64 + lane] = a[q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int nb = cs - N;
+    // ---- every B element: the A elements above it in y (the merge search of spearman_pair_kernel)
+#pragma unroll
+    for (int q0 = 0; q0 < N; q0 += G) {
+        if (q0 < N - 16 || q0 < nb) {
+            uint32_t up[G], pos[G], val[G];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                up[u] = a[q0 + u] & ~0x7Fu;
+                pos[u] = 0u;
+            }
+            if constexpr (N == 128) {
+#pragma unroll
+                for (int half = 64; half >= 1; half >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < G; u++) val[u] = comp_a[(pos[u] + uint32_t(half - 1)) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < G; u++) pos[u] = val[u] < up[u] ? pos[u] + uint32_t(half) : pos[u];
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++) val[u] = comp_a[pos[u] * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < G; u++) pos[u] = val[u] < up[u] ? pos[u] + 1u : pos[u];
+            } else {
+#pragma unroll
+                for (int step = TOP; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        const uint32_t idx = pos[u] + uint32_t(step);
+                        val[u] = comp_a[((idx <= uint32_t(N) ? idx : uint32_t(N)) - 1u) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; u++) {
+                        const uint32_t idx = pos[u] + uint32_t(step);
+                        pos[u] = (idx <= uint32_t(N) && val[u] < up[u]) ? idx : pos[u];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < G; u++) val[u] = comp_a[(pos[u] < uint32_t(N) ? pos[u] : uint32_t(N - 1)) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int q = q0 + u;
+                const bool real = q < N - 16 || q < nb;
+                const bool close = real && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
+                if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
+                    asm volatile("" ::: "memory");
+                    if (close) {
+                        const uint32_t la = low_of[(val[u] & 0x7Fu) * 64 + lane];
+                        const uint32_t lb = low_of[(N + (a[q] & 0x7Fu)) * 64 + lane];
+                        bool more = false;
+                        if (pos[u] + 1u < uint32_t(N)) more = ((comp_a[(pos[u] + 1u) * 64 + lane] ^ a[q]) < 128u);
+                        defer |= (la == lb) | more;
+                        if (la < lb) pos[u] += 1u;
+                    }
+                }
+                if (real) discordant += int32_t(uint32_t(N) - pos[u]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tau-b (Correlation.cpp:423-455): n2 = 0 for a voxel without y ties
+    const int32_t n = cs;
+    const int32_t n0 = (n * (n - 1)) / 2;
+    const int32_t n1 = prep[2 * cs];
+    const int32_t numerator = n0 - n1 - 2 * discordant;
+    const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
+    float res = float(numerator) / denominator;
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
         if (defer && !is_nan) {
@@ -1213,6 +1375,35 @@ bool launch_spearman_pair(const float* const* d_members, const float* d_prep, fl
         hipLaunchKernelGGL((spearman_pair_kernel<NN, (NN > 112 ? 1 : 2)>), dim3(blocks), dim3(64), 0, s, d_members,     \
                            d_prep, d_out,                                                                               \
                            num_voxels, cs, d_todo);                                                                     \
+        break
+    switch (n) {
+        CRF_LAUNCH_PAIR(72);
+        CRF_LAUNCH_PAIR(80);
+        CRF_LAUNCH_PAIR(88);
+        CRF_LAUNCH_PAIR(96);
+        CRF_LAUNCH_PAIR(104);
+        CRF_LAUNCH_PAIR(112);
+        CRF_LAUNCH_PAIR(120);
+        CRF_LAUNCH_PAIR(128);
+        default: return false;
+    }
+#undef CRF_LAUNCH_PAIR
+    return true;
+}
+
+// 129..256 members: kendall_pair_kernel (prep: kendall_prep_kernel's tables with stride cs); the caller runs the counting
+// kernel over d_todo afterwards.  One wave per SIMD for the register budget: at two the kernel needs > 256 registers and
+// spills 0.3 KB to scratch, at one the overflow goes to AGPRs (LDS allows 3-5 waves per CU anyway).
+bool launch_kendall_pair(const float* const* d_members, const int* d_prep, float* d_out, size_t num_voxels, int cs,
+                         uint32_t* d_todo, hipStream_t s) {
+    if (cs <= 128 || cs > 256 || !d_todo) return false;
+    (void)hipMemsetAsync(d_todo, 0, sizeof(uint32_t), s);
+    const unsigned blocks = unsigned((num_voxels + 63) / 64);
+    const int n = ((cs + 1) / 2 + 7) / 8 * 8;
+#define CRF_LAUNCH_PAIR(NN)                                                                                             \
+    case NN:                                                                                                            \
+        hipLaunchKernelGGL((kendall_pair_kernel<NN, 1>), dim3(blocks), dim3(64), 0, s, d_members,                       \
+                           d_prep, d_out, num_voxels, cs, d_todo);                                                      \
         break
     switch (n) {
         CRF_LAUNCH_PAIR(72);

@@ -29,7 +29,7 @@ def test_generic_rank_measures_bit_exact(engine, oracle, cs):
         for m, om in ((Measure.SPEARMAN, oracle_lib.SPEARMAN), (Measure.KENDALL, oracle_lib.KENDALL)):
             got = engine.compute(m, reference_values=ref_values)
             assert_bit_exact(got, oracle.field(om, ens, ref_values), f"generic {m.name} cs={cs}")
-    assert engine.last_kernel_name() == "direct_rank_kernel"
+    assert engine.last_kernel_name() == ("kendall_pair_kernel" if cs <= 256 else "direct_rank_kernel")
 
 
 @pytest.mark.parametrize("cs", [130, 200, 600])

@@ -179,28 +179,53 @@ def test_spearman_values_that_agree_in_their_upper_bits(engine, oracle, monkeypa
 
 
 PAIR_COUNTS = [129, 130, 143, 144, 145, 159, 160, 161, 176, 177, 192, 193, 208, 209, 224, 225, 239, 240, 241, 255, 256]
+PAIR_KERNEL = {Measure.SPEARMAN: "spearman_pair_kernel", Measure.KENDALL: "kendall_pair_kernel"}
 
 
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
 @pytest.mark.parametrize("pair", ["1", "0"])
 @pytest.mark.parametrize("cs", PAIR_COUNTS)
-def test_spearman_129_to_256_members_close_values(engine, oracle, monkeypatch, cs, pair):
-    """129..256 members: two sorted chunks of 32-bit composites merged through LDS (spearman_pair_kernel); values that agree
-    in their upper key bits inside a chunk AND across the chunks, runs of three / four, exact ties, NaN, +-inf -- the same
-    voxels as above.  CRF_RANK_PAIR=0: the counting kernel for every voxel."""
+def test_rank_129_to_256_members_close_values(engine, oracle, monkeypatch, cs, pair, measure, omeasure):
+    """129..256 members: two sorted chunks of 32-bit composites merged through LDS (spearman_pair_kernel /
+    kendall_pair_kernel); values that agree in their upper key bits inside a chunk AND across the chunks, runs of three /
+    four, exact ties, NaN, +-inf -- the same voxels as above.  CRF_RANK_PAIR=0: the counting kernel for every voxel."""
     monkeypatch.setenv("CRF_RANK_PAIR", pair)
     ens = _ensemble_of_close_values(cs)
-    _check(engine, oracle, ens, (1, 0, 0), Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman close values cs={cs} pair={pair}")
-    assert engine.last_kernel_name() == ("spearman_pair_kernel" if pair == "1" else "direct_rank_kernel")
+    _check(engine, oracle, ens, (1, 0, 0), measure, omeasure, f"{measure.name} close values cs={cs} pair={pair}")
+    assert engine.last_kernel_name() == (PAIR_KERNEL[measure] if pair == "1" else "direct_rank_kernel")
 
 
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
 @pytest.mark.parametrize("cs", [129, 150, 200, 256, 257])
-def test_spearman_129_to_256_members_box_ensemble_and_ties(engine, oracle, cs):
+def test_rank_129_to_256_members_box_ensemble_and_ties(engine, oracle, cs, measure, omeasure):
     """The benchmark's box ensemble (plateaus: whole voxels of exact ties -> the deferred-voxel list), a grid that is not a
-    multiple of 64 voxels, rounded values (ties everywhere), a separate reference vector with ties."""
+    multiple of 64 voxels, rounded values (ties everywhere), separate reference vectors with ties: a few tie groups, and
+    heavy ties (rounded to thirds: a tie group straddles the boundary between the two chunks, which sends every voxel of
+    the Kendall kernel to the counting kernel)."""
     ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
     ens[:, 0, 0, :] = np.round(ens[:, 0, 0, :] * 4)
     ens[7, 1, 1, 1] = np.nan
-    _check(engine, oracle, ens, (5, 6, 4), Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman box ensemble cs={cs}")
-    assert engine.last_kernel_name() == ("spearman_pair_kernel" if cs <= 256 else "direct_rank_kernel")
-    _check(engine, oracle, ens, None, Measure.SPEARMAN, oracle_lib.SPEARMAN, f"Spearman tied reference cs={cs}",
+    _check(engine, oracle, ens, (5, 6, 4), measure, omeasure, f"{measure.name} box ensemble cs={cs}")
+    assert engine.last_kernel_name() == (PAIR_KERNEL[measure] if cs <= 256 else "direct_rank_kernel")
+    few = ens[:, 3, 3, 3].copy()
+    few[5], few[9], few[cs - 1] = few[4], few[4], few[0]
+    _check(engine, oracle, ens, None, measure, omeasure, f"{measure.name} reference with a few ties cs={cs}", reference_values=few)
+    _check(engine, oracle, ens, None, measure, omeasure, f"{measure.name} heavily tied reference cs={cs}",
            reference_values=np.round(ens[:, 3, 3, 3] * 3))
+
+
+@pytest.mark.parametrize("cs", [131, 160, 255])
+def test_kendall_129_to_256_members_reference_tie_groups_at_the_chunk_boundary(engine, oracle, cs):
+    """x-tie groups ending exactly at, starting exactly at, and straddling the boundary between the two sorted chunks
+    (position N = half the member count rounded up to 8 in the reference-sorted order)."""
+    rng = np.random.default_rng(cs)
+    ens = rng.standard_normal((cs, 3, 8, 16)).astype(np.float32)
+    n = ((cs + 1) // 2 + 7) // 8 * 8
+    base = np.sort(rng.standard_normal(cs).astype(np.float32))
+    for lo, hi in [(n - 3, n - 1), (n, n + 2), (n - 2, n + 1), (n - 1, n)]:      # tie group = sorted positions lo..hi
+        ref = base.copy()
+        ref[lo:hi + 1] = ref[lo]
+        ref = ref[rng.permutation(cs)]
+        _check(engine, oracle, ens, None, Measure.KENDALL, oracle_lib.KENDALL, f"Kendall x ties {lo}..{hi} of {cs}",
+               reference_values=ref)
+        assert engine.last_kernel_name() == "kendall_pair_kernel"
