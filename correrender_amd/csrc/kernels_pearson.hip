@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void pearson_reg_lds_kernel(const f
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 321..1216 members (r03): G = 2 or 4 LANES per voxel.  A wave owns 64 / G voxels; lane group g (lanes g * 64 / G ...)
+// 289..1216 members (r03): G = 2 or 4 LANES per voxel.  A wave owns 64 / G voxels; lane group g (lanes g * 64 / G ...)
 // holds members [g * S, g * S + S) of them, S = R + L slots per lane: R in registers and L in the lane's LDS column,
 // exactly the storage of the 176..320-member kernels above, which run at two waves per SIMD and 70-88 % of the HBM
 // peak -- instead of one wave per SIMD with 384 values in VGPRs + AGPRs (37-56 %), an 8-wave relay through LDS
@@ -1027,9 +1027,13 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
 
     size_t covered = 0;
     if (ev_begin) (void)hipEventRecord(ev_begin, s);
-    // 321..1216 members: two (up to 576) or four lanes per voxel (pearson_split_kernel).  CRF_PEARSON_SPLIT=0 selects the
+    // 289..1216 members: two (up to 576) or four lanes per voxel (pearson_split_kernel).  CRF_PEARSON_SPLIT=0 selects the
     // r02 kernels (VGPRs + AGPRs at one wave per SIMD up to 384 members, the 8-wave relay up to 512, three sweeps beyond).
-    if (cs > 320 && cs <= kSplitMaxMembers && env_int("CRF_PEARSON_SPLIT", 1) != 0) {
+    // From 289 members: measured at 512x512x128 against the one-lane kernels (registers + LDS rows), % of the HBM peak:
+    // 160 members 78 vs 83, 192: 76 vs 83, 224: 75 vs 83, 256: 73 vs 87, 288: 74 vs 79, 320: 74 vs 71
+    // (profiles/r03_pearson_two_lanes_from_129_members.txt).  CRF_PEARSON_SPLIT_FROM moves the threshold (>= 129; tuning).
+    const int split_from = env_int("CRF_PEARSON_SPLIT_FROM", 289);
+    if (cs >= split_from && cs > 128 && cs <= kSplitMaxMembers && env_int("CRF_PEARSON_SPLIT", 1) != 0) {
         const int lanes = cs > 576 ? 4 : 2;  // (two lanes x 304 slots = 224 + 80 LDS rows: 0.5 KB of scratch per lane)
         const int slots = ((cs + lanes - 1) / lanes + 15) / 16 * 16;  // per lane, in steps of 16: 160 .. 304
         const size_t per_block = size_t(4) * (64 / lanes);
@@ -1051,7 +1055,12 @@ hipError_t launch_pearson(const float* const* d_members, int cs, size_t num_voxe
 #define CRF_LAUNCH_SPLIT_G(R_, L_, W_)                                                                            \
     if (lanes == 2) CRF_LAUNCH_SPLIT(R_, L_, 2, W_) else CRF_LAUNCH_SPLIT(R_, L_, 4, W_)
         switch (slots) {
-            case 160: CRF_LAUNCH_SPLIT(160, 0, 4, 2); break;  // 577..640 members
+            case 80: CRF_LAUNCH_SPLIT(80, 0, 2, 4); break;    // (tuning: CRF_PEARSON_SPLIT_FROM)
+            case 96: CRF_LAUNCH_SPLIT(96, 0, 2, 4); break;
+            case 112: CRF_LAUNCH_SPLIT(112, 0, 2, 3); break;
+            case 128: CRF_LAUNCH_SPLIT(128, 0, 2, 3); break;
+            case 144: CRF_LAUNCH_SPLIT(144, 0, 2, 2); break;
+            case 160: if (lanes == 2) CRF_LAUNCH_SPLIT(160, 0, 2, 2) else CRF_LAUNCH_SPLIT(160, 0, 4, 2) break;  // 577..640 members
             case 176: CRF_LAUNCH_SPLIT_G(176, 0, 2); break;
             case 192: CRF_LAUNCH_SPLIT_G(192, 0, 2); break;
             case 208: CRF_LAUNCH_SPLIT_G(208, 0, 2); break;

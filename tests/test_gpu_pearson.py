@@ -101,14 +101,14 @@ def test_pearson_device_path_matches_host_path(engine, oracle):
 
 
 # pearson_split_kernel (two / four lanes per voxel): every instantiation's first and last member count, both lane counts
-@pytest.mark.parametrize("cs", [321, 322, 352, 353, 416, 417, 448, 449, 480, 481, 544, 545, 576, 607, 608, 609, 640,
+@pytest.mark.parametrize("cs", [289, 290, 304, 305, 320, 321, 322, 352, 353, 416, 417, 448, 449, 480, 481, 544, 545, 576, 607, 608, 609, 640,
                                 641, 642, 704, 705, 768, 769, 832, 896, 897, 960, 961, 1088, 1089, 1152, 1153, 1216, 1217,
                                 1279, 1280, 1281])
 def test_pearson_lanes_per_voxel_kernel_boundaries(engine, oracle, cs):
     ens = synth.box_ensemble(20, 12, 9, cs, seed=cs)
     got, want = _run(engine, oracle, ens, (7, 3, 2))
     assert_bit_exact(got, want, f"pearson cs={cs}")
-    assert engine.last_kernel_name() == ("pearson_split_kernel" if 320 < cs <= 1216 else "pearson_big_kernel")
+    assert engine.last_kernel_name() == ("pearson_split_kernel" if 288 < cs <= 1216 else "pearson_big_kernel")
 
 
 @pytest.mark.parametrize("cs", [340, 500, 650, 1000])
