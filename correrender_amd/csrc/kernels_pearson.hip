@@ -471,6 +471,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void pearson_split_kernel(const flo
         }
         // (a NaN or infinite member makes the mean and therefore sd NaN: the range test fails)
         exact = sdY >= 0x1p-60f && sdY <= 0x1p60f && smallest >= __float_as_uint(0x1p-100f) - 1u;
+        // Two kinds of voxels whose result is NaN on either path, so they need not drag their wave onto the slow one --
+        // and they come in whole regions in real ensembles (missing values, masks): a NaN mean (some member is NaN:
+        // every deviation is NaN), and sd = 0 with every deviation exactly 0 (all members equal, e.g. a zero mask:
+        // the exact path computes 0 * (1 / 0) = NaN where the division gives 0 / 0 = NaN).
+        exact = exact || meanY != meanY || (sdY == 0.0f && smallest == 0xFFFFFFFFu);
     }
     if (__all(exact)) {  // exact quotients through one reciprocal per voxel
         const float rcp = 1.0f / sdY;
