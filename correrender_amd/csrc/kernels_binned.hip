@@ -165,7 +165,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void mi_binned_kernel(const float* c
         asm volatile("" : "+v"(nan_flag));
         is_nan = nan_flag != 0u;
     }
-    const bool slow = (total != cs) || !ref_all_valid;
+    // (a lane with a NaN member stores NaN whatever the histogram says: it must not drag itself -- and with it its wave,
+    // for cs^2 steps -- onto the recount; missing values come in whole regions: 256^3 x 128 with 30 % NaN voxels 75.8 ms)
+    const bool slow = !is_nan && ((total != cs) || !ref_all_valid);
     const bool any_slow = __any(slow);
     if (any_slow) {
 #pragma unroll

@@ -706,6 +706,17 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
     for (int e = 0; e < N; e++) a[e] = pos_of[e * 64 + lane];  // all reads first, then the conversions (see spearman_kernel)
 #pragma unroll
     for (int e = 0; e < N; e++) r[e] = (e < SURE || e < cs) ? float(a[e] + 1u) : 0.0f;
+    // Every member equal (a mask; such voxels come in whole regions): all cs values tie, every fractional rank is
+    // (cs + 1) / 2 (Correlation.cpp:277-303) and the tail below gives what the exact kernel would -- no deferral.
+    // (key_min also sees the pads' 0.0: it can only make the test fail, never pass wrongly.)
+    const bool all_equal = key_min == key_max && !is_nan;
+    if (__builtin_amdgcn_ballot_w64(all_equal) != 0) {  // wave-uniform
+        asm volatile("" ::: "memory");
+        const float tied_rank = 0.5f * float(cs + 1);
+#pragma unroll
+        for (int e = 0; e < N; e++) r[e] = (all_equal && (e < SURE || e < cs)) ? tied_rank : r[e];
+        defer = defer && !all_equal;
+    }
     float res = pearson_tail<N, EXACT, SURE>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
@@ -1185,8 +1196,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         if (active) todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         return;
     }
-    bool is_nan = false;
+    bool is_nan = false, all_equal = false;
     uint32_t tie_min = 0xFFFFFFFFu;
+    uint32_t tie_or = 0u;  // OR of the differences of neighbours in the sorted chunks: 0 = every member of a chunk equal
     int32_t discordant = 0;
     {
         composite_t a[CH];
@@ -1200,6 +1212,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
         for (int q = 0; q < CH; q++) {
             const uint32_t key = composite_key(a[q]);
             if (q > 0) tie_min = min(tie_min, key ^ prev);
+            if (q > 0) tie_or |= key ^ prev;
             if (q == 0) is_nan |= key < 0x007FFFFFu;
             if (q == CH - 1) is_nan |= key > 0xFF800000u;
             prev = key;
@@ -1230,6 +1243,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
                     const int p = p0 + g;
                     key[g] = composite_key(b[p]);
                     if (p > 0) tie_min = min(tie_min, key[g] ^ prev);
+                    if (p > 0) tie_or |= key[g] ^ prev;
                     if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
                     if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
                     prev = key[g];
@@ -1244,6 +1258,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
                     if (p < nB) {
                         const uint32_t key = composite_key(b[p]);
                         if (p > 0) tie_min = min(tie_min, key ^ prev);
+                        if (p > 0) tie_or |= key ^ prev;
                         if (p == 0) is_nan |= key < 0x007FFFFFu;
                         if (p == nB - 1) is_nan |= key > 0xFF800000u;
                         prev = key;
@@ -1253,6 +1268,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
             }
         }
         discordant += chunk_inversions<CHB, SURE_B>(b, nB, EXACT);
+        // every member equal (a mask: whole regions of such voxels in real ensembles): n2 = n0, no discordant pair, and
+        // with n1 = 0 (x ties went the other way above) tau = 0 / 0 -- no need to send the voxel to the exact kernel
+        all_equal = tie_or == 0u && keysA[lane] == prev;
     }
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
@@ -1260,9 +1278,9 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_split_kernel(const floa
     const int32_t numerator = n0 - n1 - 2 * discordant;  // n2 = 0: no ties in y
     const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
     float res = float(numerator) / denominator;
-    if (is_nan) res = __uint_as_float(0x7FC00000u);
+    if (is_nan || all_equal) res = __uint_as_float(0x7FC00000u);
     if (active) {
-        if (tie_min == 0u && !is_nan) {
+        if (tie_min == 0u && !is_nan && !all_equal) {
             todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         } else {
             store_result_nt(out + v, res);

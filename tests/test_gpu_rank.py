@@ -229,3 +229,27 @@ def test_kendall_129_to_256_members_reference_tie_groups_at_the_chunk_boundary(e
         _check(engine, oracle, ens, None, Measure.KENDALL, oracle_lib.KENDALL, f"Kendall x ties {lo}..{hi} of {cs}",
                reference_values=ref)
         assert engine.last_kernel_name() == "kendall_pair_kernel"
+
+
+@pytest.mark.parametrize("measure,omeasure", MEASURES)
+@pytest.mark.parametrize("cs", [20, 33, 48, 64, 65, 100, 128, 130, 200, 256])
+def test_rank_masked_voxels(engine, oracle, measure, omeasure, cs):
+    """Voxels whose members are all equal (a mask: 0, a positive and a negative constant) and voxels with missing values
+    (NaN in one / in every member), in whole waves and scattered: the fast kernels answer the all-equal ones themselves
+    (every rank (cs + 1) / 2; tau = 0 / 0) instead of deferring them to the exact kernel."""
+    rng = np.random.default_rng(cs)
+    xs, ys, zs = 64, 8, 4
+    ens = rng.standard_normal((cs, zs, ys, xs)).astype(np.float32)
+    flat = ens.reshape(cs, -1)
+    n = flat.shape[1]
+    flat[:, 0:192] = 0.0            # three whole waves
+    flat[:, 192:256] = 5.0
+    flat[:, 256:320] = -3.25
+    flat[:, 320:448] = np.nan
+    flat[cs // 2, 448:512] = np.nan
+    flat[:, 600::37] = 0.0          # scattered
+    flat[:, 601::41] = 7.5
+    flat[:-1, 700] = 1.0            # all equal but one
+    flat[1:, 701] = 1.0
+    got = _check(engine, oracle, ens, (40, 7, 3), measure, omeasure, f"{measure.name} masked voxels cs={cs}")
+    assert np.isnan(got[320:512]).all()

@@ -33,6 +33,7 @@ for cs in members_list:
     members = [block[c * n:(c + 1) * n] for c in range(cs)]
     for c in range(cs):
         eng.synth_box_member(members[c], xs, ys, zs, 0, zs, c, cs, 1234, stream)
+    torch.cuda.synchronize()   # the library's generator kernels run on another stream than torch's fill below
     if mask_kind:
         block.view(cs, n)[:, :int(mask_fraction * n)] = float("nan") if mask_kind == "nan" else 0.0
     torch.cuda.synchronize()
