@@ -748,7 +748,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_u32_kernel(const float
 template <int N, int SURE>
 __device__ __forceinline__ void sort_chunk_u32(const float* const* __restrict__ members, int first, int cs, uint32_t bytes,
                                                uint32_t byte_offset, uint8_t* __restrict__ low_col, uint32_t (&a)[N],
-                                               bool& is_nan, bool& defer, const int* __restrict__ perm = nullptr) {
+                                               bool& is_nan, bool& defer, uint32_t& key_lo, uint32_t& key_hi,
+                                               const int* __restrict__ perm = nullptr) {
+    // key_lo / key_hi: smallest key of the chunk (a pad's 0.0 included) and largest key of its members.  key_lo == key_hi
+    // means every member of the chunk is equal (masks: whole regions of such voxels); the close-pair walk below is
+    // skipped for such a lane (every position would take its branch) and the caller decides what the ties mean.
     uint32_t key_min = 0xFFFFFFFFu, key_max = 0u;
 #pragma unroll
     for (int e = 0; e < N; e++) {  // all loads first (slots past cs: out-of-range offset, no memory request)
@@ -773,7 +777,11 @@ __device__ __forceinline__ void sort_chunk_u32(const float* const* __restrict__ 
         uint32_t nan_flag = keys_hold_nan(key_min, key_max) ? 1u : 0u;
         asm volatile("" : "+v"(nan_flag));
         is_nan |= nan_flag != 0u;
+        asm volatile("" : "+v"(key_min), "+v"(key_max));
     }
+    key_lo = key_min;
+    key_hi = key_max;
+    const bool chunk_equal = key_min == key_max;
     __builtin_amdgcn_sched_barrier(0);
     SortNet32<N>::sort(a);
     pin_array(a);
@@ -782,7 +790,7 @@ __device__ __forceinline__ void sort_chunk_u32(const float* const* __restrict__ 
 #pragma unroll
     for (int q = 0; q + 1 < N; q++) {
         const bool both_real = q + 1 < SURE || first + q + 1 < cs;
-        const bool close = both_real && ((a[q] ^ a[q + 1]) < 128u);
+        const bool close = both_real && !chunk_equal && ((a[q] ^ a[q + 1]) < 128u);
         if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
             asm volatile("" ::: "memory");              // a real branch (see spearman_u32_kernel)
             if (close) {
@@ -822,16 +830,27 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
     // ---- chunk A = members [0, N) (all of them members: cs > 2 N - 16 >= N), then chunk B = members [N, 2 N), whose last
     //      16 slots may be padding.  ONE copy of the loads / keys / network / close-pair code runs twice (a rolled loop):
     //      the kernel is straight-line code far beyond the instruction cache and is paced by instruction fetch.
+    uint32_t lo_a = 0u, hi_a = 0u, lo_b = 0u, hi_b = 0u;
 #pragma unroll 1
     for (int chunk = 0; chunk < 2; chunk++) {
+        uint32_t lo, hi;
         sort_chunk_u32<N, N - 16>(members, chunk * N, cs, bytes, byte_offset, low_of + chunk * N * 64 + lane, a, is_nan,
-                                  defer);
+                                  defer, lo, hi);
         if (chunk == 0) {
+            lo_a = lo;
+            hi_a = hi;
 #pragma unroll
             for (int q = 0; q < N; q++) comp_a[q * 64 + lane] = a[q];
+        } else {
+            lo_b = lo;
+            hi_b = hi;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // every member of the voxel equal (a mask): all ranks (cs + 1) / 2, answered by the tail below; a single equal chunk
+    // is a run of ties like any other: the counting kernel's business
+    const bool all_equal = lo_a == hi_a && lo_b == hi_b && lo_a == lo_b && !is_nan;
+    defer |= (lo_a == hi_a || lo_b == hi_b) && !all_equal;
     const int nb = cs - N;  // chunk B's members sit at the sorted positions [0, nb): pads sort last
     // (This file is compiled in source order, -enable-misched=0: every group of LDS reads below is written out before
     // the first use of any of them, so that the reads of a group are in flight together.)
@@ -880,7 +899,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
             for (int u = 0; u < G; u++) {
                 const int q = q0 + u;
                 const bool real = q < N - 16 || q < nb;
-                const bool close = real && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
+                const bool close = real && !all_equal && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
                 if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
                     asm volatile("" ::: "memory");
                     if (close) {
@@ -933,6 +952,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
     // ---- computePearson2<float>(referenceRanks, ranks, cs) in member order (Correlation.cpp:141-174), ranks from LDS,
     //      16 at a time (a rank past cs reads as whatever the column holds and is not used)
     const uint8_t* rank_col = low_of + lane;
+    const float tied_rank = 0.5f * float(cs + 1);  // every fractional rank of an all-equal voxel (Correlation.cpp:277-303)
     const float n = float(cs);
     const float invN = 1.0f / n;
     const float invNm1 = 1.0f / (n - 1.0f);
@@ -944,7 +964,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
         for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; u++)
-            if (e0 + u < cs) meanY += invN * float(rk[u] + 1u);
+            if (e0 + u < cs) meanY += invN * (all_equal ? tied_rank : float(rk[u] + 1u));
     }
     float varY = 0.0f;
 #pragma unroll 1
@@ -954,7 +974,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
         for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            const float d = float(rk[u] + 1u) - meanY;
+            const float d = (all_equal ? tied_rank : float(rk[u] + 1u)) - meanY;
             if (e0 + u < cs) varY += invNm1 * d * d;
         }
     }
@@ -969,11 +989,11 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_pair_kernel(const floa
             for (int u = 0; u < 16; u++) rk[u] = rank_col[(e0 + u) * 64];
 #pragma unroll
             for (int u = 0; u < 16; u++)
-                if (e0 + u < cs) res += prep[e0 + u] * exact_div(float(rk[u] + 1u) - meanY, sdY, rcp);
+                if (e0 + u < cs) res += prep[e0 + u] * exact_div((all_equal ? tied_rank : float(rk[u] + 1u)) - meanY, sdY, rcp);
         }
     } else {
 #pragma unroll 4
-        for (int e = 0; e < cs; e++) res += prep[e] * ((float(uint32_t(rank_col[e * 64]) + 1u) - meanY) / sdY);
+        for (int e = 0; e < cs; e++) res += prep[e] * (((all_equal ? tied_rank : float(uint32_t(rank_col[e * 64]) + 1u)) - meanY) / sdY);
     }
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
@@ -1056,17 +1076,28 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_pair_kernel(const float
     __syncthreads();
     uint32_t a[N];
     int32_t discordant = 0;
+    uint32_t lo_a = 0u, hi_a = 0u, lo_b = 0u, hi_b = 0u;
 #pragma unroll 1
     for (int chunk = 0; chunk < 2; chunk++) {  // one copy of the sort and of the inversion walk, run twice
+        uint32_t lo, hi;
         sort_chunk_u32<N, N - 16>(members, chunk * N, cs, bytes, byte_offset, low_of + chunk * N * 64 + lane, a, is_nan,
-                                  defer, prep);
+                                  defer, lo, hi, prep);
         discordant += chunk_inversions_u32<N>(a, gend_tab + chunk * N, chunk * N, cs);
         if (chunk == 0) {
+            lo_a = lo;
+            hi_a = hi;
 #pragma unroll
             for (int q = 0; q < N; q++) comp_a[q * 64 + lane] = a[q];
+        } else {
+            lo_b = lo;
+            hi_b = hi;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // every member of the voxel equal (a mask): n2 = n0 and no discordant pair, answered below; a single equal chunk is a
+    // run of y ties like any other: the counting kernel's business
+    const bool all_equal = lo_a == hi_a && lo_b == hi_b && lo_a == lo_b && !is_nan;
+    defer |= (lo_a == hi_a || lo_b == hi_b) && !all_equal;
     const int nb = cs - N;
     // ---- every B element: the A elements above it in y (the merge search of spearman_pair_kernel)
 #pragma unroll
@@ -1111,7 +1142,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_pair_kernel(const float
             for (int u = 0; u < G; u++) {
                 const int q = q0 + u;
                 const bool real = q < N - 16 || q < nb;
-                const bool close = real && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
+                const bool close = real && !all_equal && pos[u] < uint32_t(N) && ((val[u] ^ a[q]) < 128u);
                 if (__builtin_amdgcn_ballot_w64(close) != 0) {  // wave-uniform, rare
                     asm volatile("" ::: "memory");
                     if (close) {
@@ -1132,12 +1163,13 @@ __global__ __launch_bounds__(64, MIN_WAVES) void kendall_pair_kernel(const float
     const int32_t n = cs;
     const int32_t n0 = (n * (n - 1)) / 2;
     const int32_t n1 = prep[2 * cs];
-    const int32_t numerator = n0 - n1 - 2 * discordant;
-    const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0));
+    const int32_t n2 = all_equal ? n0 : 0;
+    const int32_t numerator = n0 - n1 - n2 - (all_equal ? 0 : 2 * discordant);
+    const float denominator = sqrtf(float(n0 - n1)) * sqrtf(float(n0 - n2));
     float res = float(numerator) / denominator;
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
-        if (defer && !is_nan) {
+        if (defer && !is_nan && !all_equal) {
             todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         } else {
             store_result_nt(out + v, res);
