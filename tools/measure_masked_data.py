@@ -13,6 +13,7 @@ import correrender_amd as ca
 args = sys.argv[1:]
 cs = int(args[args.index("--members") + 1]) if "--members" in args else 64
 frac = float(args[args.index("--fraction") + 1]) if "--fraction" in args else 0.3
+symmetric = "--symmetric" in args   # SEPARATE_SYMMETRIC field mode: a second ensemble with the same mask
 xs = ys = zs = 256
 n = xs * ys * zs
 stream = torch.cuda.current_stream().cuda_stream
@@ -35,11 +36,23 @@ for kind in kinds:
             block.view(cs, n)[:, :int(frac * n)] = float("nan") if kind == "nan" else 0.0
     torch.cuda.synchronize()
     eng.bind_members(members)
+    if symmetric:
+        block2 = torch.empty(cs * n, dtype=torch.float32, device="cuda")
+        members2 = [block2[c * n:(c + 1) * n] for c in range(cs)]
+        for c in range(cs):
+            eng.synth_box_member(members2[c], xs, ys, zs, 0, zs, c, cs, 4321, stream)
+        torch.cuda.synchronize()
+        if kind == "nan_some":
+            block2.view(cs, n)[1::2, :int(frac * n)] = float("nan")
+        elif kind != "none":
+            block2.view(cs, n)[:, :int(frac * n)] = float("nan") if kind == "nan" else 0.0
+        torch.cuda.synchronize()
+        eng.bind_secondary_members(members2)
     eng.set_profiling(True)
     row = []
     for name in ["pearson", "spearman", "kendall", "mi_binned", "mi_kraskov"]:
         measure = ca.Measure(ca.MEASURE_IDS.index(name))
-        kw = dict(k=ca.default_kraskov_k(cs))
+        kw = dict(k=ca.default_kraskov_k(cs), symmetric=symmetric)
         if name == "mi_binned":
             kw.update(minmax_ref=(-4.0, 4.0), minmax_query=(-4.0, 4.0), num_bins=80)
         eng.compute_device(measure, out, (1, 2, 200), stream=stream, **kw)
