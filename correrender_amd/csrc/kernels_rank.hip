@@ -446,6 +446,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
     constexpr int SURE_B = CHB - 8;  // chunk B slots that are members for every cs of this instantiation
     bool is_nan = false;
     uint32_t tie_min = 0xFFFFFFFFu;  // min over compared key pairs of (k1 ^ k2): 0 iff the voxel has a tie
+    uint32_t tie_or = 0u;            // OR over the neighbours of both sorted chunks: 0 = every member of a chunk equal
+    uint32_t first_a = 0u, last_b = 0u;
     uint32_t infoB[CHB];  // for the p-th smallest element of chunk B: #{A < b_p} | slot << 8
     {
         composite_t a[CH];
@@ -459,6 +461,8 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
         for (int q = 0; q < CH; q++) {
             const uint32_t key = composite_key(a[q]);
             if (q > 0) tie_min = min(tie_min, key ^ prev);
+            if (q > 0) tie_or |= key ^ prev;
+            if (q == 0) first_a = key;
             if (q == 0) is_nan |= key < 0x007FFFFFu;
             if (q == CH - 1) is_nan |= key > 0xFF800000u;
             prev = key;
@@ -491,6 +495,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
                     const int p = p0 + g;
                     key[g] = composite_key(b[p]);
                     if (p > 0) tie_min = min(tie_min, key[g] ^ prev);
+                    if (p > 0) tie_or |= key[g] ^ prev;
                     if (p == 0) is_nan |= key[g] < 0x007FFFFFu;
                     // the largest key of the voxel sits at position nB - 1 (CHB - 1 in the exact instantiation)
                     if (EXACT ? p == CHB - 1 : guarded) is_nan |= (EXACT || p == nB - 1) && key[g] > 0xFF800000u;
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
                     if (p < nB) {
                         const uint32_t key = composite_key(b[p]);
                         if (p > 0) tie_min = min(tie_min, key ^ prev);
+                        if (p > 0) tie_or |= key ^ prev;
                         if (p == 0) is_nan |= key < 0x007FFFFFu;
                         if (p == nB - 1) is_nan |= key > 0xFF800000u;
                         prev = key;
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
                 }
             }
         }
+        last_b = prev;
     }
     __builtin_amdgcn_sched_barrier(0);
     // LDS is re-used from here on (this lane's binary searches are complete; LDS operations of a wave stay in order)
@@ -557,10 +564,20 @@ __global__ __launch_bounds__(64, MIN_WAVES) void spearman_split_kernel(const flo
 #pragma unroll
         for (int e = 0; e < CH + CHB; e++) r[e] = (EXACT || e < CH + SURE_B || e < cs) ? float(raw[e] + 1u) : 0.0f;
     }
+    // Every member equal (a mask; whole regions of such voxels in real ensembles): every fractional rank is (cs + 1) / 2
+    // (Correlation.cpp:277-303) and the tail gives what the exact kernel would -- no deferral.
+    const bool all_equal = tie_or == 0u && first_a == last_b && !is_nan;
+    if (__builtin_amdgcn_ballot_w64(all_equal) != 0) {  // wave-uniform
+        asm volatile("" ::: "memory");
+        const float tied_rank = 0.5f * float(cs + 1);
+#pragma unroll
+        for (int e = 0; e < CH + CHB; e++)
+            r[e] = (all_equal && (EXACT || e < CH + SURE_B || e < cs)) ? tied_rank : r[e];
+    }
     float res = pearson_tail<CH + CHB, EXACT, CH + SURE_B>(r, prep, cs);
     if (is_nan) res = __uint_as_float(0x7FC00000u);
     if (active) {
-        if (tie_min == 0u && !is_nan) {
+        if (tie_min == 0u && !is_nan && !all_equal) {
             todo[1 + atomicAdd(&todo[0], 1u)] = uint32_t(v);
         } else {
             store_result_nt(out + v, res);
